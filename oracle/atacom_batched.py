@@ -1,0 +1,334 @@
+"""Batch-vectorised float64 restatement of the ATACOM step (oracle; test infrastructure only).
+
+Same arithmetic as oracle/atacom_scalar.py (which follows the reference function by function), but
+vectorised over a leading batch axis so GPU parity tests at thousands of environments finish in
+seconds.  Two deliberate differences in *how* (not what) it computes, both verified against the
+scalar oracle in tests/test_oracle_batched.py:
+
+  * the orthonormal null basis and the pseudo-inverse solve come from the Householder
+    bidiagonalisation that LAPACK's dgesdd performs internally (oracle/nullspace.py docstring),
+    not from a per-environment scipy SVD call;
+  * -Jc^+ psi - Jc^+ (Kc c) is evaluated as one solve with the summed right-hand side.
+
+This is also exactly the algorithm the HIP kernels implement, so it doubles as their specification.
+"""
+import numpy as np
+
+from . import robots
+from .atacom_scalar import (ENV_CIRCLE, ENV_PLANAR, ENV_IIWA, TABLE_LENGTH, TABLE_WIDTH, GOAL_WIDTH,
+                            MALLET_RADIUS, UNIVERSAL_HEIGHT, HIT_RANGE, GOAL_POS)
+
+
+def _diag_batch(x):
+    out = np.zeros(x.shape + (x.shape[-1],))
+    idx = np.arange(x.shape[-1])
+    out[..., idx, idx] = x
+    return out
+
+
+def constraint_terms(spec, q, dq):
+    """Batched (fun_origin[B,c], J[B,c,q], b_state[B,c]); see atacom_scalar.constraint_terms."""
+    q = np.asarray(q, dtype=np.float64)
+    dq = np.asarray(dq, dtype=np.float64)
+    B = q.shape[0]
+    if spec.env_id == ENV_CIRCLE:
+        fun = np.stack([q[:, 0] ** 2 + q[:, 1] ** 2 - 1.0, -q[:, 1] - 0.5], -1)
+        J = np.zeros((B, 2, 2))
+        J[:, 0, 0], J[:, 0, 1], J[:, 1, 1] = 2 * q[:, 0], 2 * q[:, 1], -1.0
+        b = np.stack([2 * dq[:, 0] ** 2 + 2 * dq[:, 1] ** 2, np.zeros(B)], -1)
+        return fun, J, b
+    bx = TABLE_LENGTH / 2 - MALLET_RADIUS
+    by = TABLE_WIDTH / 2 - MALLET_RADIUS
+    if spec.env_id == ENV_PLANAR:
+        p, _ = robots.planar_fk(q)
+        pw = p + spec.base_xy
+        Je = robots.planar_jacobian(q)
+        acc = robots.planar_bias(q, dq, spec.bias_mode)
+        lim = robots.PLANAR_POS_LIMIT
+        fun = np.concatenate([np.stack([-pw[:, 0] - bx, -pw[:, 1] - by, pw[:, 1] - by], -1),
+                              q ** 2 - lim ** 2], -1)
+        J = np.concatenate([np.stack([-Je[:, 0], -Je[:, 1], Je[:, 1]], 1), 2 * _diag_batch(q)], 1)
+        b = np.concatenate([np.stack([-acc[:, 0], -acc[:, 1], acc[:, 1]], -1), 2 * dq ** 2], -1)
+        return fun, J, b
+    if spec.env_id == ENV_IIWA:
+        pe, _ = robots.iiwa_frame(q, 'ee')
+        p4, _ = robots.iiwa_frame(q, 'link_4')
+        p7, _ = robots.iiwa_frame(q, 'link_7')
+        Je = robots.iiwa_frame_jacobian(q, 'ee')
+        J4 = robots.iiwa_frame_jacobian(q, 'link_4')
+        J7 = robots.iiwa_frame_jacobian(q, 'link_7')
+        ae = robots.iiwa_frame_bias(q, dq, 'ee', spec.bias_mode)
+        a4 = robots.iiwa_frame_bias(q, dq, 'link_4', spec.bias_mode)
+        a7 = robots.iiwa_frame_bias(q, dq, 'link_7', spec.bias_mode)
+        xw = pe[:, 0] + spec.base_xy[0]
+        yw = pe[:, 1] + spec.base_xy[1]
+        lim = robots.IIWA_POS_LIMIT[:6]
+        fun = np.concatenate([np.stack([pe[:, 2] - UNIVERSAL_HEIGHT, -xw - bx, -yw - by, yw - by,
+                                        -p4[:, 2] + 0.36, -p7[:, 2] + 0.25], -1), q ** 2 - lim ** 2], -1)
+        J = np.concatenate([np.stack([Je[:, 2], -Je[:, 0], -Je[:, 1], Je[:, 1], -J4[:, 2], -J7[:, 2]], 1),
+                            2 * _diag_batch(q)], 1)
+        b = np.concatenate([np.stack([ae[:, 2], -ae[:, 0], -ae[:, 1], ae[:, 1], -a4[:, 2], -a7[:, 2]], -1),
+                            2 * dq ** 2], -1)
+        return fun, J, b
+    raise ValueError(spec.env_id)
+
+
+def mallet_xy_world(spec, q):
+    if spec.env_id == ENV_PLANAR:
+        return robots.planar_fk(q)[0] + spec.base_xy
+    return robots.iiwa_frame(q, 'ee')[0][:, :2] + spec.base_xy
+
+
+# ------------------------------------------------------------------ batched dgebd2 / rref
+def _larfg(alpha, x):
+    """Batched dlarfg.  alpha[B], x[B,L] -> beta[B], v[B,L], tau[B]."""
+    xnorm = np.sqrt((x * x).sum(-1))
+    nz = xnorm != 0.0
+    beta = np.where(nz, -np.copysign(np.hypot(alpha, xnorm), alpha), alpha)
+    safe = np.where(nz, beta, 1.0)
+    tau = np.where(nz, (beta - alpha) / safe, 0.0)
+    den = np.where(nz, alpha - beta, 1.0)
+    v = np.where(nz[:, None], x / den[:, None], 0.0)
+    return beta, v, tau
+
+
+def bidiag_solve_null(Jc, rhs, k):
+    """For each Jc[b] (c x n, full row rank): x = Jc^+ rhs[b]  and the orthonormal null basis N[b]
+    (n x k) = last k columns of P = G(1)...G(c) -- the basis LAPACK's SVD returns (nullspace.py)."""
+    a = np.array(Jc, dtype=np.float64, copy=True)
+    y = np.array(rhs, dtype=np.float64, copy=True)
+    B, m, n = a.shape
+    d = np.zeros((B, m))
+    e = np.zeros((B, max(m - 1, 0)))
+    Gv, Gt = [], []
+    for i in range(m):
+        beta, v, taup = _larfg(a[:, i, i], a[:, i, i + 1:])
+        vv = np.concatenate([np.ones((B, 1)), v], -1)
+        Gv.append(vv)
+        Gt.append(taup)
+        d[:, i] = beta
+        if i < m - 1:
+            w = np.einsum('brc,bc->br', a[:, i + 1:, i:], vv)
+            a[:, i + 1:, i:] -= taup[:, None, None] * w[:, :, None] * vv[:, None, :]
+            beta, u, tauq = _larfg(a[:, i + 1, i], a[:, i + 2:, i])
+            uu = np.concatenate([np.ones((B, 1)), u], -1)
+            e[:, i] = beta
+            w = np.einsum('br,brc->bc', uu, a[:, i + 1:, i + 1:])
+            a[:, i + 1:, i + 1:] -= tauq[:, None, None] * uu[:, :, None] * w[:, None, :]
+            wy = (uu * y[:, i + 1:]).sum(-1)
+            y[:, i + 1:] -= (tauq * wy)[:, None] * uu
+    z = np.zeros((B, n))
+    for i in range(m):
+        prev = e[:, i - 1] * z[:, i - 1] if i > 0 else 0.0
+        z[:, i] = (y[:, i] - prev) / d[:, i]
+    X = np.zeros((B, n, k + 1))
+    X[:, :, 0] = z
+    X[:, np.arange(m, n), np.arange(1, k + 1)] = 1.0
+    for i in range(m - 1, -1, -1):
+        vv, tau = Gv[i], Gt[i]
+        w = np.einsum('bc,bck->bk', vv, X[:, i:, :])
+        X[:, i:, :] -= tau[:, None, None] * vv[:, :, None] * w[:, None, :]
+    return X[:, :, 0], X[:, :, 1:]
+
+
+def rref_tol(N, tol):
+    """Batched null_space_coordinate.rref(N, row_vectors=False, tol) (lines 40-79)."""
+    V = np.array(np.swapaxes(N, 1, 2), dtype=np.float64, copy=True)       # B x k x n
+    B, m, n = V.shape
+    i = np.zeros(B, dtype=np.int64)
+    ar = np.arange(B)
+    rows = np.arange(m)[None, :]
+    for j in range(n):
+        active = i < m
+        if not active.any():
+            break
+        col = np.abs(V[:, :, j])
+        col = np.where(rows >= i[:, None], col, -1.0)
+        kk = np.argmax(col, axis=1)                       # first maximum, like np.argmax
+        p = col[ar, kk]
+        piv = active & (p > tol)
+        skip = active & ~piv
+        # negligible column: zero it from row i down
+        zero_mask = skip[:, None] & (rows >= i[:, None])
+        V[:, :, j] = np.where(zero_mask, 0.0, V[:, :, j])
+        if piv.any():
+            b = ar[piv]
+            ib, kb = i[piv], kk[piv]
+            tmp = V[b, ib, :].copy()
+            V[b, ib, :] = V[b, kb, :]
+            V[b, kb, :] = tmp
+            prow = V[b, ib, j:] / V[b, ib, j][:, None]
+            colj = V[b, :, j].copy()
+            V[b, :, j:] -= colj[:, :, None] * prow[:, None, :]
+            V[b, ib, j:] = prow
+            i[piv] += 1
+    return np.swapaxes(V, 1, 2)
+
+
+# ------------------------------------------------------------------ the batched environment
+class BatchedAtacomEnv:
+    def __init__(self, spec, batch, init_q=None, init_dq=None, init_puck=None):
+        self.spec, self.B = spec, batch
+        nq = spec.dim_q
+        if init_q is None:
+            init_q = {ENV_CIRCLE: np.array([-1.0, 0.0]), ENV_PLANAR: robots.PLANAR_INIT_Q,
+                      ENV_IIWA: np.zeros(6)}[spec.env_id]
+        self.init_q = np.broadcast_to(np.asarray(init_q, dtype=np.float64), (batch, nq)).copy()
+        self.init_dq = np.zeros((batch, nq)) if init_dq is None else \
+            np.broadcast_to(np.asarray(init_dq, dtype=np.float64), (batch, nq)).copy()
+        pk = np.array([HIT_RANGE[0].mean(), HIT_RANGE[1].mean(), 0, 0, 0, 0.0]) if init_puck is None \
+            else np.asarray(init_puck, dtype=np.float64)
+        self.init_puck = np.broadcast_to(pk, (batch, 6)).copy()
+        self.q = np.zeros((batch, nq))
+        self.dq = np.zeros((batch, nq))
+        self.s = np.zeros((batch, spec.n_g))
+        self.puck = np.zeros((batch, 6))
+        self.has_hit = np.zeros(batch, dtype=bool)
+        self.r_hit = np.zeros(batch)
+        self.vel_hit_x = np.zeros(batch)
+        self.t = np.zeros(batch, dtype=np.int64)
+        self.stat_sum = np.zeros(batch)
+        self.stat_cnt = np.zeros(batch, dtype=np.int64)
+        self.stat_cmax = np.full(batch, -np.inf)
+        self.stat_dqmax = np.full(batch, -np.inf)
+        self.reset()
+
+    def slack_init(self, q, dq):
+        sp = self.spec
+        fun, J, _ = constraint_terms(sp, q, dq)
+        g = (fun + sp.K * np.einsum('bcq,bq->bc', J, dq))[:, sp.n_f:]
+        return np.sqrt(np.maximum(-2.0 * g, 0.0))
+
+    def reset(self, mask=None):
+        m = np.ones(self.B, dtype=bool) if mask is None else np.asarray(mask, dtype=bool)
+        self.q[m], self.dq[m], self.puck[m] = self.init_q[m], self.init_dq[m], self.init_puck[m]
+        self.has_hit[m], self.r_hit[m], self.vel_hit_x[m], self.t[m] = False, 0.0, 0.0, 0
+        if m.any():
+            self.s[m] = self.slack_init(self.q[m], self.dq[m])
+        return self.observation()
+
+    def set_state(self, q, dq, s=None, puck=None):
+        self.q[:], self.dq[:] = q, dq
+        if puck is not None:
+            self.puck[:] = puck
+        self.s[:] = self.slack_init(self.q, self.dq) if s is None else s
+
+    def observation(self):
+        sp = self.spec
+        if sp.env_id == ENV_CIRCLE:
+            return np.concatenate([self.q, self.dq], -1)
+        pk = self.puck
+        return np.concatenate([pk[:, 0:1] - sp.base_xy[0], pk[:, 1:2] - sp.base_xy[1], pk[:, 2:6],
+                               self.q, self.dq], -1)
+
+    def tangent_space_accel(self, q, dq, s, alpha, terms=None):
+        sp = self.spec
+        nq, nf, ng, nc, B = sp.dim_q, sp.n_f, sp.n_g, sp.n_c, q.shape[0]
+        fun, J, bst = constraint_terms(sp, q, dq) if terms is None else terms
+        Jdq = np.einsum('bcq,bq->bc', J, dq)
+        Jc = np.zeros((B, nc, nq + ng))
+        Jc[:, :, :nq] = sp.K[None, :, None] * J + 0.0     # '+ 0.0': -0.0 -> +0.0 like the reference's matmul
+        idx = np.arange(ng)
+        Jc[:, nf + idx, nq + idx] = s
+        psi = Jdq + sp.K * bst
+        c = fun + sp.K * Jdq
+        c[:, nf:] += 0.5 * s ** 2
+        x, N = bidiag_solve_null(Jc, psi + sp.Kc * c, sp.n_null)
+        Nr = rref_tol(N, sp.rref_tol)
+        return -x + np.einsum('bnk,bk->bn', Nr, alpha)
+
+    def acc_truncation(self, dq, ddq):
+        sp = self.spec
+        up = np.maximum(np.minimum(sp.acc_max, -sp.Kq * (dq - sp.vel_max)), -sp.acc_max)
+        lo = np.minimum(np.maximum(-sp.acc_max, -sp.Kq * (dq + sp.vel_max)), sp.acc_max)
+        return np.clip(ddq, lo, up)
+
+    def step(self, action):
+        sp = self.spec
+        nq = sp.dim_q
+        alpha = np.clip(np.asarray(action, dtype=np.float64), -1.0, 1.0) * sp.alpha_max
+        if sp.env_id == ENV_CIRCLE:
+            c_pre = np.stack([np.abs(self.q[:, 0] ** 2 + self.q[:, 1] ** 2 - 1), -self.q[:, 1] - 0.5], -1)
+            dq_pre = np.abs(self.dq) - 1.0
+            self._log(c_pre.max(-1), c_pre.max(-1), dq_pre.max(-1))
+            mu = self.tangent_space_accel(self.q, self.dq, self.s, alpha)
+            self.s = self.s + mu[:, nq:] * sp.dt
+            ddq = self.acc_truncation(self.dq, mu[:, :nq])
+            a = np.clip(ddq / sp.acc_max, -1.0, 1.0) * 10.0
+            self.q = self.q + (self.dq * sp.dt + a * sp.dt ** 2 / 2)
+            self.dq = self.dq + a * sp.dt
+            reward = np.exp(-np.hypot(1.0 - self.q[:, 0], self.q[:, 1]))
+            absorbing = np.zeros(self.B, dtype=bool)
+        else:
+            q_ctl, dq_ctl = self.q.copy(), self.dq.copy()
+            q_sim, dq_sim = self.q.copy(), self.dq.copy()
+            terms = constraint_terms(sp, q_ctl, dq_ctl)
+            for _ in range(sp.substeps):
+                if not sp.hold_q:
+                    q_ctl, dq_ctl = q_sim.copy(), dq_sim.copy()
+                    terms = constraint_terms(sp, q_ctl, dq_ctl)
+                mu = self.tangent_space_accel(q_ctl, dq_ctl, self.s, alpha, terms)
+                self.s = self.s + mu[:, nq:] * sp.dt
+                ddq = self.acc_truncation(dq_ctl, mu[:, :nq])
+                dq_sim = np.clip(dq_sim + ddq * sp.dt, -1.5 * sp.vel_max, 1.5 * sp.vel_max)
+                q_sim = q_sim + dq_sim * sp.dt
+                self._puck_substep()
+            self.q, self.dq = q_sim, dq_sim
+            absorbing = self._is_absorbing()
+            reward = self._reward(alpha, absorbing)
+            fun, _, _ = constraint_terms(sp, self.q, np.zeros_like(self.q))
+            c_i = fun.copy()
+            c_i[:, :sp.n_f] = np.abs(c_i[:, :sp.n_f])
+            cm = c_i.max(-1)
+            self._log(cm, cm, (np.abs(self.dq) - sp.vel_max).max(-1))
+        self.t += 1
+        return self.observation(), reward, absorbing, {}
+
+    def _puck_substep(self):
+        sp = self.spec
+        self.puck[:, 0:3] += self.puck[:, 3:6] * sp.dt
+        v = np.hypot(self.puck[:, 3], self.puck[:, 4])
+        new_hit = (~self.has_hit) & (v > 0.1)
+        self.vel_hit_x = np.where(new_hit, self.puck[:, 3], self.vel_hit_x)
+        self.has_hit |= new_hit
+
+    def _is_absorbing(self):
+        sp = self.spec
+        bnd = np.array([TABLE_LENGTH, TABLE_WIDTH]) / 2
+        out = np.any(np.abs(self.puck[:, :2]) > bnd, -1)
+        out |= np.any(np.abs(mallet_xy_world(sp, self.q)) - bnd > 0.02, -1)
+        out |= self.has_hit & (np.hypot(self.puck[:, 3], self.puck[:, 4]) < 0.01)
+        return out
+
+    def _reward(self, alpha, absorbing):
+        sp = self.spec
+        pp = self.puck[:, :2]
+        goal = (pp[:, 0] - TABLE_LENGTH / 2 > 0) & (np.abs(pp[:, 1]) - GOAL_WIDTH < 0)
+        ee = mallet_xy_world(sp, self.q)
+        d = pp - ee
+        dist = np.sqrt((d * d).sum(-1))
+        g = GOAL_POS - pp
+        gn = np.sqrt((g * g).sum(-1))
+        cosang = np.clip(((g / gn[:, None]) * (d / dist[:, None])).sum(-1), 0, 1)
+        r_app = np.exp(-8 * (dist - 0.08)) * cosang
+        upd = (~absorbing) & (~self.has_hit)
+        self.r_hit = np.where(upd, r_app, self.r_hit)
+        r = np.where(absorbing, np.where(goal, 80.0, 0.0),
+                     np.where(self.has_hit, 1 + self.r_hit + self.vel_hit_x * 0.1, r_app))
+        return r - sp.action_penalty * np.sqrt((alpha * alpha).sum(-1))
+
+    def _log(self, c_for_avg, c_for_max, dq_for_max):
+        self.stat_sum += c_for_avg
+        self.stat_cnt += 1
+        self.stat_cmax = np.maximum(self.stat_cmax, c_for_max)
+        self.stat_dqmax = np.maximum(self.stat_dqmax, dq_for_max)
+
+    def get_constraints_logs(self, clear=True):
+        out = (float(self.stat_sum.sum() / max(self.stat_cnt.sum(), 1)), float(self.stat_cmax.max()),
+               float(self.stat_dqmax.max()))
+        if clear:
+            self.stat_sum[:] = 0
+            self.stat_cnt[:] = 0
+            self.stat_cmax[:] = -np.inf
+            self.stat_dqmax[:] = -np.inf
+        return out

@@ -1,0 +1,400 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the reference's OWN Python modules (build container only).
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+The reference (/root/reference, read-only) is imported unchanged; its MushroomRL dependency is
+satisfied by the duck-typed stub in oracle/_mushroom_stub (our code).  Nothing of the reference is
+copied: the fixtures hold inputs and the outputs the reference computed for them.  /root/reference
+does not exist on the GPU box, so this script never runs there -- only its committed outputs travel.
+
+Golden sets:
+  G1 pinv_null      reference null_space_coordinate.pinv_null on random / structured J_c
+  G2 rref           reference rref(tol=0.05) on those null bases + small-pivot cases; rref == sympy
+  G3 constraints    ViabilityConstraint / ConstraintsSet fun, K_J, b on the circle callables
+  G4 circle         CircleEnvAtacom trajectories (state, s, reward, act_a/b/err, constraint logs)
+  G5 generic        the reference's generic AtacomEnvWrapper driven at the planar (6x9) and iiwa
+                    (12x17) shapes by THIS build's kinematics callables and dynamics model, 4 physics
+                    sub-steps per step (reproduces the zero-order hold of q, dq -- quirk Q1)
+  G6 tables         acc_truncation and _compute_slack_variables
+  G7 logs           get_constraints_logs aggregation
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(HERE, '_mushroom_stub'))
+sys.path.insert(0, '/root/reference')
+sys.path.insert(0, REPO)
+
+import matplotlib  # noqa: E402
+matplotlib.use('Agg')
+import numpy as np  # noqa: E402
+
+from atacom.atacom import AtacomEnvWrapper  # noqa: E402  (reference)
+from atacom.constraints import ViabilityConstraint, ConstraintsSet  # noqa: E402  (reference)
+from atacom.utils.null_space_coordinate import pinv_null, rref, rref_sympy  # noqa: E402  (reference)
+from atacom.environments.circular_motion import CircleEnvAtacom  # noqa: E402  (reference)
+from mushroom_rl.core import MDPInfo  # noqa: E402  (stub)
+from mushroom_rl.utils.spaces import Box  # noqa: E402  (stub)
+
+from oracle import robots  # noqa: E402
+from oracle import atacom_scalar as osc  # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+SHAPES = {'circle': (2, 3, 1), 'planar': (6, 9, 3), 'iiwa': (12, 17, 5)}   # (c, n, k)
+
+
+def structured_jc(rng, c, n, nf):
+    """[K J | diag(s)] with the f rows carrying no slack, like atacom.py:151-165."""
+    nq = n - (c - nf)
+    Jc = np.zeros((c, n))
+    Jc[:, :nq] = rng.standard_normal((c, nq)) * rng.uniform(0.1, 2.0, (c, 1))
+    s = rng.uniform(0.0, 1.5, c - nf)
+    Jc[nf:, nq:] = np.diag(s)
+    return Jc
+
+
+def gen_nullspace():
+    rng = np.random.default_rng(20260928)
+    out = {}
+    for name, (c, n, k) in SHAPES.items():
+        nf = {'circle': 1, 'planar': 0, 'iiwa': 1}[name]
+        mats = []
+        for _ in range(24):
+            mats.append(rng.standard_normal((c, n)))
+        for _ in range(24):
+            mats.append(structured_jc(rng, c, n, nf))
+        for _ in range(8):                          # some slack entries exactly / nearly zero
+            m = structured_jc(rng, c, n, nf)
+            idx = rng.integers(nf, c)
+            m[idx, (n - (c - nf)) + (idx - nf)] = 0.0 if rng.random() < 0.5 else 1e-3
+            mats.append(m)
+        for _ in range(8):                          # tiny slacks: forces the rref tolerance branch
+            m = structured_jc(rng, c, n, nf)
+            m[nf:, n - (c - nf):] *= 0.02
+            mats.append(m)
+        mats = np.array(mats)
+        pinvs, nulls, rrefs = [], [], []
+        for m in mats:
+            B, Q = pinv_null(m)
+            assert Q.shape[1] == k, (name, Q.shape)
+            pinvs.append(B)
+            nulls.append(Q)
+            rrefs.append(rref(Q[:, :k], row_vectors=False, tol=0.05))
+        out[name + '_Jc'] = mats
+        out[name + '_pinv'] = np.array(pinvs)
+        out[name + '_null'] = np.array(nulls)
+        out[name + '_rref'] = np.array(rrefs)
+    # rank-deficient input (duplicated row): reference returns a wider null basis
+    m = rng.standard_normal((6, 9))
+    m[3] = -m[2]
+    B, Q, rank = pinv_null(m, return_rank=True)
+    out['rankdef_Jc'], out['rankdef_pinv'], out['rankdef_null'], out['rankdef_rank'] = m, B, Q, rank
+    # rref (default tol) == sympy rref, the reference's own rref_test (null_space_coordinate.py:172-179)
+    As, Rs = [], []
+    for _ in range(40):
+        mm, nn = rng.integers(1, 10, 2)
+        V = rng.standard_normal((mm, nn))
+        r1, r2 = rref(V), rref_sympy(V)
+        assert np.isclose(r1, r2).all()
+        Apad = np.full((9, 9), np.nan)
+        Apad[:mm, :nn] = V
+        Rpad = np.full((9, 9), np.nan)
+        Rpad[:mm, :nn] = r1
+        As.append(Apad)
+        Rs.append(Rpad)
+    out['rref_default_in'], out['rref_default_out'] = np.array(As), np.array(Rs)
+    # explicit small-pivot cases for rref(tol=0.05), row_vectors=False
+    cases_in, cases_out = [], []
+    for _ in range(32):
+        V = np.linalg.qr(rng.standard_normal((9, 3)))[0]
+        V[rng.integers(0, 3), :] *= 0.01          # a column of V^T below the tolerance
+        cases_in.append(V)
+        cases_out.append(rref(V, row_vectors=False, tol=0.05))
+    out['rref_tol_in'], out['rref_tol_out'] = np.array(cases_in), np.array(cases_out)
+    np.savez_compressed(os.path.join(OUT, 'nullspace.npz'), **out)
+    print('nullspace.npz', {k: v.shape for k, v in out.items() if hasattr(v, 'shape')})
+
+
+def gen_constraints():
+    rng = np.random.default_rng(7)
+    f = ConstraintsSet(2)
+    f.add_constraint(ViabilityConstraint(2, 1, fun=CircleEnvAtacom.circle_fun, J=CircleEnvAtacom.circle_J,
+                                         b=CircleEnvAtacom.circle_b, K=0.1))
+    g = ConstraintsSet(2)
+    g.add_constraint(ViabilityConstraint(2, 1, fun=CircleEnvAtacom.height_fun, J=CircleEnvAtacom.height_J,
+                                         b=CircleEnvAtacom.height_b, K=2))
+    q = rng.uniform(-1.5, 1.5, (64, 2))
+    dq = rng.uniform(-1.5, 1.5, (64, 2))
+    rec = {k: [] for k in ['f_fun', 'f_fun_origin', 'f_KJ', 'f_b', 'g_fun', 'g_fun_origin', 'g_KJ', 'g_b']}
+    for qi, dqi in zip(q, dq):
+        for nm, cs in (('f', f), ('g', g)):
+            rec[nm + '_fun'].append(cs.fun(qi, dqi))
+            rec[nm + '_fun_origin'].append(cs.fun(qi, dqi, origin_constr=True))
+            rec[nm + '_KJ'].append(cs.K_J(qi))
+            rec[nm + '_b'].append(cs.b(qi, dqi))
+    np.savez_compressed(os.path.join(OUT, 'constraints_circle.npz'), q=q, dq=dq,
+                        **{k: np.array(v) for k, v in rec.items()})
+    print('constraints_circle.npz')
+
+
+def random_circle_state(rng):
+    """A valid reset state in the spirit of circle_base.py:36-42, from a seeded generator."""
+    y = rng.uniform(-0.5, 1)
+    x = np.sqrt(1 - y ** 2) * np.sign(rng.uniform(-1, 1))
+    dx = rng.uniform(-1, 1)
+    dy = -x * dx / y
+    v = np.array([dx, dy])
+    v = v / np.linalg.norm(v) * rng.uniform(0, 1)
+    return np.array([x, y, v[0], v[1]])
+
+
+def gen_circle():
+    rng = np.random.default_rng(11)
+    T = 500
+    n_fixed, n_zero_vel, n_ref_random = 1, 8, 8
+    n_traj = n_fixed + n_zero_vel + n_ref_random
+    actions = rng.uniform(-1.3, 1.3, (n_traj, T, 1))
+    actions[1] = 1.0          # saturated actions drive the point into the height constraint
+    actions[2] = -1.0
+    rec = {k: [] for k in ['obs', 's', 'reward', 'act_a', 'act_b', 'act_err', 'logs']}
+    inits, s0 = [], []
+    for i, act in enumerate(actions):
+        env = CircleEnvAtacom(horizon=T)
+        if i < n_fixed:
+            env.reset()
+        elif i < n_fixed + n_zero_vel:
+            # an injected state must pass the reference's guard (circle_base.py:46-49), which tests
+            # x*dx - y*dy (not the tangency x*dx + y*dy): zero velocity always passes
+            st = random_circle_state(rng)
+            env.reset(np.array([st[0], st[1], 0.0, 0.0]))
+        else:
+            # the reference's own random initialisation (circle_base.py:36-42) draws from numpy's
+            # global generator and bypasses the guard; seed it so the fixture is reproducible
+            env.env.random_init = True
+            np.random.seed(1000 + i)
+            env.reset()
+        inits.append(env.state.copy())
+        s0.append(env.s.copy())
+        tr = {k: [] for k in rec if k != 'logs'}
+        for a in act:
+            obs, r, ab, _ = env.step(a)
+            assert ab is False
+            tr['obs'].append(obs)
+            tr['s'].append(env.s.copy())
+            tr['reward'].append(r)
+            tr['act_a'].append(env._act_a.copy())
+            tr['act_b'].append(env._act_b.copy())
+            tr['act_err'].append(env._act_err.copy())
+        for k in tr:
+            rec[k].append(np.array(tr[k]))
+        rec['logs'].append(np.array(env.get_constraints_logs()))
+    np.savez_compressed(os.path.join(OUT, 'circle_traj.npz'), init=np.array(inits), s0=np.array(s0),
+                        actions=actions, **{k: np.array(v) for k, v in rec.items()})
+    print('circle_traj.npz', np.array(rec['obs']).shape)
+    # the reset-state guard itself (circle_base.py:46-49): a tangential velocity is REJECTED by the
+    # reference (sign quirk), an off-circle point too
+    env = CircleEnvAtacom()
+    guard_states = np.array([[0.5, 0.5, 0.0, 0.0], [0.6, 0.8, 0.4, -0.3], [0.6, 0.8, 0.4, 0.3],
+                             [0.6, 0.8, 0.0, 0.0], [-1.0, 0.0, 0.0, 0.7]])
+    guard_ok = []
+    for st in guard_states:
+        try:
+            env.reset(st.copy())
+            guard_ok.append(True)
+        except ValueError:
+            guard_ok.append(False)
+    np.savez_compressed(os.path.join(OUT, 'circle_reset_guard.npz'), states=guard_states,
+                        accepted=np.array(guard_ok))
+    print('reset guard', guard_ok)
+
+
+# ------------------------------------------------------------------ G5: generic wrapper, our kinematics
+class _KinematicBase:
+    """Fake base env for the reference wrapper: this build's dynamics model (oracle docstring), the
+    MushroomRL PyBullet.step loop shape (n_intermediate_steps x [_compute_action -> apply]) and the
+    observation layout [puck pose 3, puck vel 3, q, dq] (env_single.py:82-120)."""
+
+    def __init__(self, spec, init_q):
+        self.spec = spec
+        nq = spec.dim_q
+        obs_dim = 6 + 2 * nq
+        self._mdp_info = MDPInfo(Box(-np.inf * np.ones(obs_dim), np.inf * np.ones(obs_dim)),
+                                 Box(-np.ones(nq), np.ones(nq)), spec.gamma, spec.horizon)
+        self.step_action_function = None
+        self.init_q = init_q
+        self.puck = np.array([osc.HIT_RANGE[0].mean(), osc.HIT_RANGE[1].mean(), 0, 0, 0, 0.0])
+        self.sub_mu = []
+
+    @property
+    def info(self):
+        return self._mdp_info
+
+    def _create_observation(self, sim_state):
+        return sim_state
+
+    def _obs(self):
+        b = self.spec.base_xy
+        return np.concatenate([[self.puck[0] - b[0], self.puck[1] - b[1], self.puck[2]], self.puck[3:],
+                               self.q_sim, self.dq_sim])
+
+    def reset(self, state=None):
+        nq = self.spec.dim_q
+        if state is None:
+            self.q_sim, self.dq_sim = self.init_q.copy(), np.zeros(nq)
+        else:
+            self.q_sim, self.dq_sim = state[:nq].copy(), state[nq:].copy()
+        return self._obs()
+
+    def step(self, alpha):
+        sp = self.spec
+        for _ in range(sp.substeps):
+            ddq = self.step_action_function(self._obs(), alpha)
+            self.dq_sim = np.clip(self.dq_sim + ddq * sp.dt, -1.5 * sp.vel_max, 1.5 * sp.vel_max)
+            self.q_sim = self.q_sim + self.dq_sim * sp.dt
+        return self._obs(), 0.0, False, {}
+
+
+def _reference_constraints(spec):
+    """Reference ViabilityConstraint / ConstraintsSet objects fed with this build's callables."""
+    nq, nf = spec.dim_q, spec.n_f
+    zero = np.zeros(nq)
+
+    def rows(lo, hi):
+        fun = lambda q: osc.constraint_terms(spec, q, zero)[0][lo:hi]           # noqa: E731
+        J = lambda q: osc.constraint_terms(spec, q, zero)[1][lo:hi]             # noqa: E731
+        b = lambda q, dq: osc.constraint_terms(spec, q, dq)[2][lo:hi]           # noqa: E731
+        return fun, J, b
+
+    f = None
+    if nf > 0:
+        f = ConstraintsSet(nq)
+        fun, J, b = rows(0, nf)
+        f.add_constraint(ViabilityConstraint(nq, nf, fun=fun, J=J, b=b, K=spec.K[0]))
+    g = ConstraintsSet(nq)
+    n_cart = spec.n_g - nq
+    fun, J, b = rows(nf, nf + n_cart)
+    g.add_constraint(ViabilityConstraint(nq, n_cart, fun=fun, J=J, b=b, K=spec.K[nf]))
+    fun, J, b = rows(nf + n_cart, nf + spec.n_g)
+    g.add_constraint(ViabilityConstraint(nq, nq, fun=fun, J=J, b=b, K=spec.K[nf + n_cart]))
+    return f, g
+
+
+class _GenericAtacom(AtacomEnvWrapper):
+    """The reference wrapper with the three abstract hooks filled in (atacom.py:81-88)."""
+
+    def __init__(self, spec, init_q):
+        base = _KinematicBase(spec, init_q)
+        f, g = _reference_constraints(spec)
+        super().__init__(base, spec.dim_q, f=f, g=g, Kc=spec.Kc[0], vel_max=spec.vel_max.copy(),
+                         acc_max=spec.acc_max.copy(), Kq=spec.Kq.copy(), time_step=spec.dt)
+        self.sub_mu = []
+
+    def _get_q(self, state):
+        return state[6:6 + self.dims['q']]
+
+    def _get_dq(self, state):
+        return state[6 + self.dims['q']:]
+
+    def acc_to_ctrl_action(self, ddq):
+        self.sub_mu.append(self._act_a + self._act_b + self._act_err)
+        return ddq
+
+
+IIWA_INIT_Q = None
+
+
+def iiwa_init_q():
+    global IIWA_INIT_Q
+    if IIWA_INIT_Q is None:
+        ok, q = robots.iiwa_clik(np.array([0.65, 0.0, osc.UNIVERSAL_HEIGHT]), np.diag([-1.0, 1.0, -1.0]),
+                                 np.zeros(7))
+        assert ok
+        IIWA_INIT_Q = q[:6].copy()
+    return IIWA_INIT_Q
+
+
+def gen_generic():
+    rng = np.random.default_rng(5)
+    out = {}
+    for name, spec_fn, init_q in (('planar', osc.planar_spec, robots.PLANAR_INIT_Q),
+                                  ('iiwa', osc.iiwa_spec, iiwa_init_q())):
+        spec = spec_fn()
+        nq, k = spec.dim_q, spec.n_null
+        T, n_traj = 120, 8
+        inits, acts = [], []
+        while len(inits) < n_traj:
+            q0 = init_q + rng.normal(0, 0.05, nq)
+            dq0 = rng.normal(0, 0.05, nq) if len(inits) % 2 else np.zeros(nq)
+            fun, J, _ = osc.constraint_terms(spec, q0, dq0)
+            if np.all((fun + spec.K * (J @ dq0))[spec.n_f:] < -1e-3):
+                inits.append(np.concatenate([q0, dq0]))
+        acts = rng.uniform(-1.3, 1.3, (n_traj, T, k))
+        acts[0] = 1.0            # saturated / sign-pattern actions push against the limits and make
+        acts[1] = -1.0           # the rref tolerance branch fire
+        acts[2] = np.where(np.arange(k) % 2 == 0, 1.0, -1.0)
+        acts[3, :, :] = rng.choice([-1.0, 1.0], size=(T, k))
+        rec = {kk: [] for kk in ['obs', 's', 'mu', 'logs']}
+        for init, act in zip(inits, acts):
+            env = _GenericAtacom(spec, init_q)
+            env.reset(init.copy())
+            s0 = env.s.copy()
+            tr = {'obs': [], 's': [], 'mu': []}
+            for a in act:
+                env.sub_mu.clear()
+                obs, r, ab, _ = env.step(a)
+                tr['obs'].append(obs)
+                tr['s'].append(env.s.copy())
+                tr['mu'].append(np.array(env.sub_mu))
+            for kk in tr:
+                rec[kk].append(np.array(tr[kk]))
+            rec['logs'].append(np.array(env.get_constraints_logs()))
+            rec.setdefault('s0', []).append(s0)
+        out[name + '_init'] = np.array(inits)
+        out[name + '_actions'] = acts
+        out[name + '_init_q'] = np.array(init_q)
+        for kk, v in rec.items():
+            out[name + '_' + kk] = np.array(v)
+        print(name, 'generic traj', out[name + '_obs'].shape, 'c_max', np.array(rec['logs'])[:, 1].max())
+    np.savez_compressed(os.path.join(OUT, 'generic_traj.npz'), **out)
+
+
+def gen_tables():
+    rng = np.random.default_rng(3)
+    out = {}
+    for name, spec_fn, init_q in (('planar', osc.planar_spec, robots.PLANAR_INIT_Q),
+                                  ('iiwa', osc.iiwa_spec, iiwa_init_q())):
+        spec = spec_fn()
+        env = _GenericAtacom(spec, init_q)
+        dq = rng.uniform(-1.8, 1.8, (128, spec.dim_q)) * spec.vel_max
+        ddq = rng.uniform(-15, 15, (128, spec.dim_q))
+        out[name + '_trunc_dq'], out[name + '_trunc_ddq'] = dq, ddq
+        out[name + '_trunc_out'] = np.array([env.acc_truncation(a, b) for a, b in zip(dq, ddq)])
+        qs = init_q + rng.normal(0, 0.4, (128, spec.dim_q))
+        dqs = rng.normal(0, 0.5, (128, spec.dim_q))
+        ss = []
+        for q, d in zip(qs, dqs):
+            env.q, env.dq = q, d
+            env._compute_slack_variables()
+            ss.append(env.s.copy())
+        out[name + '_slack_q'], out[name + '_slack_dq'], out[name + '_slack_s'] = qs, dqs, np.array(ss)
+    # G7: log aggregation (atacom.py:207-216) on a recorded log
+    spec = osc.planar_spec()
+    env = _GenericAtacom(spec, robots.PLANAR_INIT_Q)
+    logs = rng.uniform(-1, 0.2, (50, 2))
+    env.constr_logs = [list(x) for x in logs]
+    out['agg_logs'] = logs
+    out['agg_out'] = np.array(env.get_constraints_logs())
+    assert len(env.constr_logs) == 0
+    np.savez_compressed(os.path.join(OUT, 'tables.npz'), **out)
+    print('tables.npz')
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    todo = sys.argv[1:] or ['nullspace', 'constraints', 'circle', 'generic', 'tables']
+    for name in todo:
+        globals()['gen_' + name]()
