@@ -1,0 +1,143 @@
+/* atacom_hip.h -- C ABI of libatacom_hip.so, the MI355X (gfx950) batched ATACOM environment-step engine.
+ *
+ * The reference (PuzeLiu/rl_on_manifold) is pure Python and has no FFI; this header is the boundary a
+ * maintainer would bind with ctypes (INTEGRATION.md shows the stub).  Each entry point names the
+ * reference interface it replaces (paths relative to /root/reference/).  Plain C types only; every
+ * d_* pointer is DEVICE memory owned by the caller (e.g. a torch ROCm tensor's data_ptr()); `stream`
+ * is a hipStream_t (0 / NULL = the null stream).  All work is enqueued asynchronously on `stream`
+ * except atacom_get_stats, which synchronises that stream to return three numbers to the host.
+ *
+ * Floating-point type: every float buffer of a handle has the element type chosen at creation
+ * (cfg.dtype: 0 = float32 -- the production path; 1 = float64 -- same kernels instantiated in double,
+ * used to show algorithmic identity with the float64 reference to ~1e-10).
+ *
+ * Return value: 0 on success, negative on error (ATACOM_E_*); atacom_last_error() gives the message of
+ * the last failing call on the calling thread.  No C++ exception crosses this boundary.
+ * Thread-safety: a handle must not be used from two threads at once (the reference is single-threaded
+ * too); distinct handles are independent.
+ */
+#ifndef ATACOM_HIP_H
+#define ATACOM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ATACOM_ENV_CIRCLE 0 /* atacom/environments/circular_motion/circle_atacom.py:6  CircleEnvAtacom      */
+#define ATACOM_ENV_PLANAR 1 /* atacom/environments/planar_air_hockey/atacom_air_hockey.py:11 (task 'H')     */
+#define ATACOM_ENV_IIWA 2   /* atacom/environments/iiwa_air_hockey/iiwa_hit_atacom.py:10 (env '7H')         */
+
+#define ATACOM_F32 0
+#define ATACOM_F64 1
+
+#define ATACOM_OK 0
+#define ATACOM_E_INVALID (-1)     /* bad argument / inconsistent config */
+#define ATACOM_E_HIP (-2)         /* a HIP runtime call failed */
+#define ATACOM_E_UNSUPPORTED (-3)
+
+#define ATACOM_MAX_C 12 /* constraint rows (iiwa: 1 equality + 11 inequalities) */
+#define ATACOM_MAX_Q 6  /* controlled joints */
+
+/* POD configuration.  atacom_default_config() fills the reference's constants for an environment:
+ *   circle  circle_atacom.py:9-18   (K_f .1, K_g 2, Kc 100, acc_max 10, vel_max 1, Kq 20, dt .01, horizon 500)
+ *   planar  atacom_air_hockey.py:12-43 + examples/planar_air_hockey_exp.py:102-105
+ *   iiwa    iiwa_hit_atacom.py:11-40   + examples/iiwa_air_hockey_exp.py:104-107
+ * Row order of K / Kc: equality rows (f) first, then inequality rows (g), as atacom.py:151-165 stacks them. */
+typedef struct atacom_config {
+    int32_t struct_size; /* = sizeof(atacom_config); checked by atacom_create */
+    int32_t env_id;      /* ATACOM_ENV_* */
+    int32_t batch;       /* number of independent environments held by the handle */
+    int32_t dtype;       /* ATACOM_F32 / ATACOM_F64 */
+    int32_t substeps;    /* n_intermediate_steps: physics sub-steps per env step (circle 1, others 4) */
+    int32_t horizon;     /* MDPInfo.horizon */
+    int32_t hold_q;      /* 1 = reference behaviour: q, dq frozen across the sub-steps of one step
+                            (atacom.py:124-126 never refreshes self.q / self.dq) */
+    int32_t bias_mode;   /* 0 = reference "classical acceleration" w x v (quirk Q2); 1 = exact dJ/dt dq */
+    int32_t auto_reset;  /* 1 = an env whose step returned last=1 is re-initialised inside the same call
+                            (what mushroom_rl.Core does between steps); the returned obs is still the
+                            terminal observation, the next call starts from the reset state */
+    int32_t reserved0;
+    double dt;           /* time_step */
+    double rref_tol;     /* 0.05, atacom.py:128 */
+    double action_penalty; /* env_hitting.py:10,68 */
+    double gamma;
+    double K[ATACOM_MAX_C];       /* ViabilityConstraint.K per row */
+    double Kc[ATACOM_MAX_C];      /* AtacomEnvWrapper.K_c per row */
+    double vel_max[ATACOM_MAX_Q];
+    double acc_max[ATACOM_MAX_Q];
+    double Kq[ATACOM_MAX_Q];
+    double pos_limit[ATACOM_MAX_Q]; /* joint position limits (upper; lower = -upper) */
+    double base_xy[2];            /* robot base in the table frame (env_base.py:50) */
+    double link[3];               /* planar arm link lengths */
+} atacom_config;
+
+typedef struct atacom_handle atacom_handle;
+
+/* Static shape information of an environment (what AtacomEnvWrapper.dims / MDPInfo expose). */
+typedef struct atacom_dims {
+    int32_t dim_q, n_f, n_g, n_null /* = action dim, atacom.py:39,51 */, obs_dim;
+    int32_t state_dim;      /* floats per env in atacom_get_state / atacom_set_state:
+                               [q, dq, s, puck(6), has_hit, r_hit, vel_hit_x, t] */
+    int32_t init_state_dim; /* floats per env in atacom_reset's d_init_state: [q, dq] (+ puck(6) for planar/iiwa) */
+} atacom_dims;
+
+int atacom_default_config(int32_t env_id, atacom_config* out);
+int atacom_get_dims(int32_t env_id, atacom_dims* out);
+
+/* Replaces constructing the wrapper + base env (atacom.py:10-79; circle_base.py:18-31; env_hitting.py:8-21).
+ * Allocates the persistent per-env state (structure-of-arrays planes) on `device`. */
+int atacom_create(const atacom_config* cfg, int device, atacom_handle** out);
+int atacom_destroy(atacom_handle* h);
+
+/* AtacomEnvWrapper.reset (atacom.py:93-98) for every env whose mask byte is non-zero (all if d_mask is
+ * NULL): state <- stored initial state, slack s <- sqrt(max(-2 g(q, dq), 0)) (atacom.py:145-149), flags
+ * and step counter cleared.  If d_init_state is non-NULL its rows ([batch, init_state_dim]) first replace
+ * the stored initial state of the masked envs (base_env.reset(state), circle_base.py:33-51,
+ * env_hitting.py:23-37).  d_obs ([batch, obs_dim], may be NULL) receives the observation of ALL envs. */
+int atacom_reset(atacom_handle* h, const uint8_t* d_mask, const void* d_init_state, void* d_obs, void* stream);
+
+/* AtacomEnvWrapper.step (atacom.py:106-115) for the whole batch: action clip + scale, `substeps` x
+ * [step_action_function (atacom.py:123-139) -> dynamics], absorbing / reward / observation, constraint
+ * statistics.  d_action [batch, n_null]; d_obs [batch, obs_dim]; d_reward [batch]; d_absorbing [batch]
+ * (uint8); d_last [batch] (uint8, may be NULL) = absorbing or step counter reached the horizon. */
+int atacom_step(atacom_handle* h, const void* d_action, void* d_obs, void* d_reward, uint8_t* d_absorbing,
+                uint8_t* d_last, void* stream);
+
+/* n_steps consecutive steps in ONE kernel launch (per-env state stays in registers between steps).
+ * d_actions [n_steps, batch, n_null]; outputs are time-major: d_obs [n_steps, batch, obs_dim] holds the
+ * observation BEFORE each step, d_next_obs (may be NULL) the observation after it, d_reward / d_absorbing /
+ * d_last [n_steps, batch] -- the (s, a, r, s', absorbing, last) tuples mushroom_rl.Core collects. */
+int atacom_rollout(atacom_handle* h, int32_t n_steps, const void* d_actions, void* d_obs, void* d_next_obs,
+                   void* d_reward, uint8_t* d_absorbing, uint8_t* d_last, void* stream);
+
+/* get_constraints_logs (atacom.py:207-216; circle_base.py:109-115): out = {c_avg, c_max, c_dq_max} over every
+ * (env, step) logged since the last clear.  Synchronises `stream`. */
+int atacom_get_stats(atacom_handle* h, double out[3], int32_t clear, void* stream);
+
+/* Parity injection / checkpointing: d_state [batch, state_dim]. */
+int atacom_get_state(atacom_handle* h, void* d_state, void* stream);
+int atacom_set_state(atacom_handle* h, const void* d_state, void* stream);
+
+/* Stand-alone batched primitives (no handle), for parity tests of individual reference functions.
+ *   atacom_nullspace: for n matrices Jc [n, c, c+k] (row-major) and right-hand sides [n, c]:
+ *     d_x [n, c+k]        = Jc^+ rhs                         (pinv_null, null_space_coordinate.py:8-26)
+ *     d_null [n, c+k, k]  = orthonormal null basis           (same function, second output)
+ *     d_rref [n, c+k, k]  = rref(null, row_vectors=False, tol) (null_space_coordinate.py:40-79)
+ *   shape is given by env_id (circle 2x3, planar 6x9, iiwa 12x17).
+ *   atacom_constraint_terms: q, dq [n, dim_q] -> fun [n, c], J [n, c, dim_q], b [n, c]: the fun / J / b
+ *     callables handed to ViabilityConstraint (circle_atacom.py:47-70, atacom_air_hockey.py:78-107,
+ *     iiwa_hit_atacom.py:70-139).  cfg supplies geometry and bias_mode. */
+int atacom_nullspace(int32_t env_id, int32_t dtype, int32_t n, const void* d_Jc, const void* d_rhs, double tol,
+                     void* d_x, void* d_null, void* d_rref, void* stream);
+int atacom_constraint_terms(const atacom_config* cfg, int32_t n, const void* d_q, const void* d_dq, void* d_fun,
+                            void* d_J, void* d_b, void* stream);
+
+const char* atacom_last_error(void);
+const char* atacom_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATACOM_HIP_H */

@@ -1,0 +1,89 @@
+"""ctypes binding of libatacom_hip.so (include/atacom_hip.h).  No numerics here.
+
+The library is the product: if it is missing or cannot be loaded this module raises -- there is no
+CPU / PyTorch fallback anywhere in the package.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libatacom_hip.so')
+
+ENV_CIRCLE, ENV_PLANAR, ENV_IIWA = 0, 1, 2
+F32, F64 = 0, 1
+MAX_C, MAX_Q = 12, 6
+
+EXPORTS = ['atacom_default_config', 'atacom_get_dims', 'atacom_create', 'atacom_destroy', 'atacom_reset',
+           'atacom_step', 'atacom_rollout', 'atacom_get_stats', 'atacom_get_state', 'atacom_set_state',
+           'atacom_nullspace', 'atacom_constraint_terms', 'atacom_last_error', 'atacom_version']
+
+
+class AtacomConfig(C.Structure):
+    """Mirror of `atacom_config` (include/atacom_hip.h)."""
+    _fields_ = [('struct_size', C.c_int32), ('env_id', C.c_int32), ('batch', C.c_int32), ('dtype', C.c_int32),
+                ('substeps', C.c_int32), ('horizon', C.c_int32), ('hold_q', C.c_int32), ('bias_mode', C.c_int32),
+                ('auto_reset', C.c_int32), ('reserved0', C.c_int32),
+                ('dt', C.c_double), ('rref_tol', C.c_double), ('action_penalty', C.c_double), ('gamma', C.c_double),
+                ('K', C.c_double * MAX_C), ('Kc', C.c_double * MAX_C), ('vel_max', C.c_double * MAX_Q),
+                ('acc_max', C.c_double * MAX_Q), ('Kq', C.c_double * MAX_Q), ('pos_limit', C.c_double * MAX_Q),
+                ('base_xy', C.c_double * 2), ('link', C.c_double * 3)]
+
+
+class AtacomDims(C.Structure):
+    _fields_ = [('dim_q', C.c_int32), ('n_f', C.c_int32), ('n_g', C.c_int32), ('n_null', C.c_int32),
+                ('obs_dim', C.c_int32), ('state_dim', C.c_int32), ('init_state_dim', C.c_int32)]
+
+
+class AtacomError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the shared library with argtypes set.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AtacomError("libatacom_hip.so is not built (%s). Run `python -m rl_on_manifold_amd.build` -- "
+                          "there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, u8p = C.c_void_p, C.c_int32, C.c_void_p
+    lib.atacom_default_config.argtypes = [i32, C.POINTER(AtacomConfig)]
+    lib.atacom_get_dims.argtypes = [i32, C.POINTER(AtacomDims)]
+    lib.atacom_create.argtypes = [C.POINTER(AtacomConfig), C.c_int, C.POINTER(vp)]
+    lib.atacom_destroy.argtypes = [vp]
+    lib.atacom_reset.argtypes = [vp, u8p, vp, vp, vp]
+    lib.atacom_step.argtypes = [vp, vp, vp, vp, u8p, u8p, vp]
+    lib.atacom_rollout.argtypes = [vp, i32, vp, vp, vp, vp, u8p, u8p, vp]
+    lib.atacom_get_stats.argtypes = [vp, C.POINTER(C.c_double * 3), i32, vp]
+    lib.atacom_get_state.argtypes = [vp, vp, vp]
+    lib.atacom_set_state.argtypes = [vp, vp, vp]
+    lib.atacom_nullspace.argtypes = [i32, i32, i32, vp, vp, C.c_double, vp, vp, vp, vp]
+    lib.atacom_constraint_terms.argtypes = [C.POINTER(AtacomConfig), i32, vp, vp, vp, vp, vp, vp]
+    lib.atacom_last_error.restype = C.c_char_p
+    lib.atacom_version.restype = C.c_char_p
+    for name in EXPORTS:
+        if name not in ('atacom_last_error', 'atacom_version'):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise AtacomError(load().atacom_last_error().decode())
+
+
+def default_config(env_id):
+    cfg = AtacomConfig()
+    check(load().atacom_default_config(env_id, C.byref(cfg)))
+    return cfg
+
+
+def get_dims(env_id):
+    d = AtacomDims()
+    check(load().atacom_get_dims(env_id, C.byref(d)))
+    return d

@@ -1,0 +1,63 @@
+"""Build libatacom_hip.so in-tree with hipcc for gfx950 (no GPU needed: hipcc cross-compiles).
+
+    python -m rl_on_manifold_amd.build [--force]
+
+One translation unit per environment (they compile in parallel) + the C-ABI host file, linked into
+rl_on_manifold_amd/libatacom_hip.so.  The .so is git-ignored but travels to the GPU box with gpurun.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libatacom_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+ARCH = 'gfx950'
+FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+UNITS = ['atacom_circle.hip', 'atacom_planar.hip', 'atacom_iiwa.hip', 'atacom_capi.cpp']
+
+
+def _sources():
+    out = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    out.append(os.path.join(os.path.dirname(HERE), 'include', 'atacom_hip.h'))
+    return out
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in _sources())
+
+
+def _compile(unit):
+    src = os.path.join(CSRC, unit)
+    obj = os.path.join(CSRC, os.path.splitext(unit)[0] + '.o')
+    cmd = [HIPCC] + FLAGS + (['-x', 'hip'] if unit.endswith('.cpp') else []) + ['-c', src, '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (unit, ' '.join(cmd), r.stderr[-4000:]))
+    return obj
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    if verbose:
+        print('[atacom] building %s for %s ...' % (os.path.basename(LIB), ARCH), flush=True)
+    with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:
+        objs = list(ex.map(_compile, UNITS))
+    cmd = [HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n%s\n%s' % (' '.join(cmd), r.stderr[-4000:]))
+    for o in objs:
+        os.remove(o)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(LIB)

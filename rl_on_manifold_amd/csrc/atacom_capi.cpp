@@ -1,0 +1,286 @@
+// C-ABI host side of libatacom_hip.so (see include/atacom_hip.h).  Owns the per-handle device state
+// and dispatches to the per-environment launch tables; contains no numerics.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "atacom_ops.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ATACOM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+    } while (0)
+
+const atacom::EnvOps* get_ops(int env_id, int dtype) {
+    if (dtype != ATACOM_F32 && dtype != ATACOM_F64) return nullptr;
+    switch (env_id) {
+        case ATACOM_ENV_CIRCLE: return atacom::ops_circle(dtype);
+        case ATACOM_ENV_PLANAR: return atacom::ops_planar(dtype);
+        case ATACOM_ENV_IIWA: return atacom::ops_iiwa(dtype);
+        default: return nullptr;
+    }
+}
+
+constexpr int kStatBlocks = 256;
+
+// default initial state rows: [q, dq, puck(6)]
+void default_init_row(int env_id, std::vector<double>& row) {
+    const double puck[6] = {-0.4, 0.0, 0.0, 0.0, 0.0, 0.0};   // centre of hit_range, env_hitting.py:11,27
+    if (env_id == ATACOM_ENV_CIRCLE) {
+        row = {-1.0, 0.0, 0.0, 0.0};                            // circle_base.py:44
+    } else if (env_id == ATACOM_ENV_PLANAR) {
+        row = {-0.9273, 0.9273, M_PI / 2, 0, 0, 0};             // MushroomRL planar init pose
+    } else {
+        // CLIK pose for the tip at (0.65, 0, 0.1505), R = diag(-1, 1, -1) (env_single.py:39-44, kinematics.py);
+        // value computed by oracle/robots.py:iiwa_clik and pinned in tests/test_oracle_kinematics.py
+        row = {0.0, 0.7135214629060707, 0.0, -0.5024756033561426, 0.0, 1.9256631778550268, 0, 0, 0, 0, 0, 0};
+    }
+    row.insert(row.end(), puck, puck + 6);
+}
+
+}  // namespace
+
+struct atacom_handle {
+    atacom_config cfg;
+    int device;
+    const atacom::EnvOps* ops;
+    void* f;        // float planes [n_planes][batch]
+    int* ip;        // int planes [n_iplanes][batch]
+    double* partial_dev;
+    double* partial_host;
+};
+
+extern "C" {
+
+const char* atacom_last_error(void) { return g_err.c_str(); }
+const char* atacom_version(void) { return "atacom_hip 0.1 (gfx950)"; }
+
+int atacom_get_dims(int32_t env_id, atacom_dims* out) {
+    const atacom::EnvOps* ops = get_ops(env_id, ATACOM_F32);
+    if (!ops || !out) return fail(ATACOM_E_INVALID, "atacom_get_dims: bad env_id or null output");
+    out->dim_q = ops->nq; out->n_f = ops->nf; out->n_g = ops->ng; out->n_null = ops->nk;
+    out->obs_dim = ops->obs_dim; out->state_dim = ops->state_dim; out->init_state_dim = ops->init_dim;
+    return ATACOM_OK;
+}
+
+int atacom_default_config(int32_t env_id, atacom_config* c) {
+    if (!c) return fail(ATACOM_E_INVALID, "atacom_default_config: null output");
+    std::memset(c, 0, sizeof(*c));
+    c->struct_size = (int32_t)sizeof(atacom_config);
+    c->env_id = env_id;
+    c->batch = 1;
+    c->dtype = ATACOM_F32;
+    c->hold_q = 1;
+    c->bias_mode = 0;
+    c->auto_reset = 0;
+    c->rref_tol = 0.05;          // atacom.py:128
+    c->gamma = 0.99;
+    c->action_penalty = 1e-3;    // env_hitting.py:10
+    if (env_id == ATACOM_ENV_CIRCLE) {
+        // circle_atacom.py:7-18
+        c->substeps = 1; c->horizon = 500; c->dt = 0.01; c->hold_q = 0;
+        c->K[0] = 0.1; c->K[1] = 2.0;
+        for (int i = 0; i < 2; ++i) { c->Kc[i] = 100.0; c->vel_max[i] = 1.0; c->acc_max[i] = 10.0; c->Kq[i] = 20.0; }
+    } else if (env_id == ATACOM_ENV_PLANAR) {
+        // atacom_air_hockey.py:12-43; robot data: DESIGN.md "Planar robot" (MushroomRL URDF, not in the tree)
+        c->substeps = 4; c->horizon = 120; c->dt = 1.0 / 240.0;
+        const double vel[3] = {M_PI / 2, M_PI / 2, 2 * M_PI / 3};
+        const double lim[3] = {2.9670597283903604, 2.0943951023931953, 2.0943951023931953};
+        const double link[3] = {0.55, 0.44, 0.44};
+        for (int i = 0; i < 6; ++i) { c->K[i] = i < 3 ? 0.5 : 1.0; c->Kc[i] = 240.0; }
+        for (int i = 0; i < 3; ++i) {
+            c->vel_max[i] = vel[i]; c->acc_max[i] = 10.0; c->Kq[i] = 2 * 10.0 / vel[i];
+            c->pos_limit[i] = lim[i]; c->link[i] = link[i];
+        }
+        c->base_xy[0] = -1.51; c->base_xy[1] = 0.0;
+    } else if (env_id == ATACOM_ENV_IIWA) {
+        // iiwa_hit_atacom.py:11-40; limits urdf/iiwa_1.urdf:74,112,149,186,223,260; base env_base.py:50
+        c->substeps = 4; c->horizon = 120; c->dt = 1.0 / 240.0;
+        const double vel[6] = {1.4835298641951802, 1.4835298641951802, 1.7453292519943295,
+                               1.3089969389957472, 2.2689280275926285, 2.356194490192345};
+        const double lim[6] = {2.9670597283903604, 2.0943951023931953, 2.9670597283903604,
+                               2.0943951023931953, 2.9670597283903604, 2.0943951023931953};
+        c->K[0] = 0.1;
+        for (int i = 1; i < 6; ++i) c->K[i] = 0.5;
+        for (int i = 6; i < 12; ++i) c->K[i] = 1.0;
+        for (int i = 0; i < 12; ++i) c->Kc[i] = 240.0;
+        for (int i = 0; i < 6; ++i) {
+            c->vel_max[i] = vel[i]; c->acc_max[i] = 10.0; c->Kq[i] = 4 * 10.0 / vel[i]; c->pos_limit[i] = lim[i];
+        }
+        c->base_xy[0] = -1.51; c->base_xy[1] = 0.0;
+    } else {
+        return fail(ATACOM_E_INVALID, "atacom_default_config: unknown env_id");
+    }
+    return ATACOM_OK;
+}
+
+int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
+    if (!cfg || !out) return fail(ATACOM_E_INVALID, "atacom_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(atacom_config))
+        return fail(ATACOM_E_INVALID, "atacom_create: atacom_config.struct_size mismatch (ABI)");
+    const atacom::EnvOps* ops = get_ops(cfg->env_id, cfg->dtype);
+    if (!ops) return fail(ATACOM_E_INVALID, "atacom_create: unknown env_id / dtype");
+    if (cfg->batch <= 0 || cfg->substeps <= 0 || cfg->horizon <= 0 || !(cfg->dt > 0))
+        return fail(ATACOM_E_INVALID, "atacom_create: batch, substeps, horizon and dt must be positive");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(ATACOM_E_INVALID, "atacom_create: no such device");
+    HIP_TRY(hipSetDevice(device));
+    atacom_handle* h = new atacom_handle();
+    h->cfg = *cfg;
+    h->device = device;
+    h->ops = ops;
+    h->f = nullptr; h->ip = nullptr; h->partial_dev = nullptr; h->partial_host = nullptr;
+    const size_t B = (size_t)cfg->batch;
+    hipError_t e = hipMalloc(&h->f, ops->elem * ops->n_planes * B);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->ip, sizeof(int) * ops->n_iplanes * B);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->partial_dev, sizeof(double) * 4 * kStatBlocks);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->partial_host, sizeof(double) * 4 * kStatBlocks);
+    if (e != hipSuccess) {
+        atacom_destroy(h);
+        return fail(ATACOM_E_HIP, std::string("atacom_create: allocation failed: ") + hipGetErrorString(e));
+    }
+    HIP_TRY(hipMemset(h->f, 0, ops->elem * ops->n_planes * B));
+    HIP_TRY(hipMemset(h->ip, 0, sizeof(int) * ops->n_iplanes * B));
+    // default initial state for every env, then a full reset
+    std::vector<double> row;
+    default_init_row(cfg->env_id, row);
+    std::vector<char> bytes(row.size() * ops->elem);
+    for (size_t i = 0; i < row.size(); ++i) {
+        if (ops->elem == 4) reinterpret_cast<float*>(bytes.data())[i] = (float)row[i];
+        else reinterpret_cast<double*>(bytes.data())[i] = row[i];
+    }
+    void* drow = nullptr;
+    HIP_TRY(hipMalloc(&drow, bytes.size()));
+    HIP_TRY(hipMemcpy(drow, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+    ops->fill_init(h->cfg, h->f, h->ip, drow, nullptr);
+    ops->clear_stats(h->cfg, h->f, h->ip, nullptr);
+    ops->reset(h->cfg, h->f, h->ip, nullptr, nullptr, nullptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(drow));
+    *out = h;
+    return ATACOM_OK;
+}
+
+int atacom_destroy(atacom_handle* h) {
+    if (!h) return ATACOM_OK;
+    (void)hipSetDevice(h->device);
+    if (h->f) (void)hipFree(h->f);
+    if (h->ip) (void)hipFree(h->ip);
+    if (h->partial_dev) (void)hipFree(h->partial_dev);
+    if (h->partial_host) (void)hipHostFree(h->partial_host);
+    delete h;
+    return ATACOM_OK;
+}
+
+int atacom_reset(atacom_handle* h, const uint8_t* d_mask, const void* d_init_state, void* d_obs, void* stream) {
+    if (!h) return fail(ATACOM_E_INVALID, "atacom_reset: null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    h->ops->reset(h->cfg, h->f, h->ip, d_mask, d_init_state, d_obs, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+
+int atacom_step(atacom_handle* h, const void* d_action, void* d_obs, void* d_reward, uint8_t* d_absorbing,
+                uint8_t* d_last, void* stream) {
+    if (!h) return fail(ATACOM_E_INVALID, "atacom_step: null handle");
+    if (!d_action || !d_obs || !d_reward || !d_absorbing)
+        return fail(ATACOM_E_INVALID, "atacom_step: d_action, d_obs, d_reward and d_absorbing are required");
+    HIP_TRY(hipSetDevice(h->device));
+    h->ops->step(h->cfg, h->f, h->ip, d_action, d_obs, d_reward, d_absorbing, d_last, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+
+int atacom_rollout(atacom_handle* h, int32_t n_steps, const void* d_actions, void* d_obs, void* d_next_obs,
+                   void* d_reward, uint8_t* d_absorbing, uint8_t* d_last, void* stream) {
+    if (!h) return fail(ATACOM_E_INVALID, "atacom_rollout: null handle");
+    if (n_steps <= 0) return fail(ATACOM_E_INVALID, "atacom_rollout: n_steps must be positive");
+    if (!d_actions || !d_obs || !d_reward || !d_absorbing || !d_last)
+        return fail(ATACOM_E_INVALID, "atacom_rollout: all buffers except d_next_obs are required");
+    HIP_TRY(hipSetDevice(h->device));
+    h->ops->rollout(h->cfg, n_steps, h->f, h->ip, d_actions, d_obs, d_next_obs, d_reward, d_absorbing, d_last,
+                    (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+
+int atacom_get_stats(atacom_handle* h, double out[3], int32_t clear, void* stream) {
+    if (!h || !out) return fail(ATACOM_E_INVALID, "atacom_get_stats: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = std::min(kStatBlocks, (h->cfg.batch + 255) / 256);
+    h->ops->stats(h->cfg, h->f, h->ip, h->partial_dev, nb, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->partial_host, h->partial_dev, sizeof(double) * 4 * nb, hipMemcpyDeviceToHost, s));
+    if (clear) h->ops->clear_stats(h->cfg, h->f, h->ip, s);
+    HIP_TRY(hipStreamSynchronize(s));
+    double sum = 0.0, cnt = 0.0, cmax = -INFINITY, dqmax = -INFINITY;
+    for (int i = 0; i < nb; ++i) {
+        sum += h->partial_host[4 * i + 0];
+        cnt += h->partial_host[4 * i + 1];
+        cmax = std::fmax(cmax, h->partial_host[4 * i + 2]);
+        dqmax = std::fmax(dqmax, h->partial_host[4 * i + 3]);
+    }
+    out[0] = cnt > 0 ? sum / cnt : NAN;    // np.mean of an empty log is nan as well
+    out[1] = cmax;
+    out[2] = dqmax;
+    return ATACOM_OK;
+}
+
+int atacom_get_state(atacom_handle* h, void* d_state, void* stream) {
+    if (!h || !d_state) return fail(ATACOM_E_INVALID, "atacom_get_state: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    h->ops->get_state(h->cfg, h->f, h->ip, d_state, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+
+int atacom_set_state(atacom_handle* h, const void* d_state, void* stream) {
+    if (!h || !d_state) return fail(ATACOM_E_INVALID, "atacom_set_state: null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    h->ops->set_state(h->cfg, h->f, h->ip, d_state, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+
+int atacom_nullspace(int32_t env_id, int32_t dtype, int32_t n, const void* d_Jc, const void* d_rhs, double tol,
+                     void* d_x, void* d_null, void* d_rref, void* stream) {
+    const atacom::EnvOps* ops = get_ops(env_id, dtype);
+    if (!ops) return fail(ATACOM_E_INVALID, "atacom_nullspace: unknown env_id / dtype");
+    if (n <= 0 || !d_Jc) return fail(ATACOM_E_INVALID, "atacom_nullspace: n must be positive and d_Jc non-null");
+    ops->nullspace(n, d_Jc, d_rhs, tol, d_x, d_null, d_rref, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+
+int atacom_constraint_terms(const atacom_config* cfg, int32_t n, const void* d_q, const void* d_dq, void* d_fun,
+                            void* d_J, void* d_b, void* stream) {
+    if (!cfg || cfg->struct_size != (int32_t)sizeof(atacom_config))
+        return fail(ATACOM_E_INVALID, "atacom_constraint_terms: bad config");
+    const atacom::EnvOps* ops = get_ops(cfg->env_id, cfg->dtype);
+    if (!ops) return fail(ATACOM_E_INVALID, "atacom_constraint_terms: unknown env_id / dtype");
+    if (n <= 0 || !d_q || !d_dq || !d_fun || !d_J || !d_b)
+        return fail(ATACOM_E_INVALID, "atacom_constraint_terms: null buffer");
+    ops->terms(*cfg, n, d_q, d_dq, d_fun, d_J, d_b, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+
+}  // extern "C"

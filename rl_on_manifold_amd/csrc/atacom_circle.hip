@@ -1,0 +1,7 @@
+// Device code of the circle environment (float32 production path + float64 parity build).
+#include "atacom_ops_impl.h"
+namespace atacom {
+const EnvOps* ops_circle(int dtype) {
+    return dtype == ATACOM_F64 ? Ops<double, Circle>::table() : Ops<float, Circle>::table();
+}
+}  // namespace atacom

@@ -1,0 +1,521 @@
+// Kernels of the batched ATACOM step, templated on the scalar type and the environment.
+//
+// Mapping (DESIGN.md "Kernel design"): ONE ENVIRONMENT PER LANE, 64 consecutive environments per
+// wavefront, one wavefront per workgroup.  Persistent per-env state lives in HBM as structure-of-arrays
+// planes [field][env] so a wave's loads/stores of one field are a single coalesced 256-B (f32) segment;
+// all per-env matrices (J_c 12x17, null basis 17x5, ...) live in VGPRs -- the kernels are compiled for
+// one wave per SIMD (__launch_bounds__(64)) to get the full 512-register budget.
+// The four physics sub-steps of an env step, the observation / reward / termination logic and the
+// constraint statistics are fused in one kernel; k_rollout additionally keeps the state in registers
+// across many env steps (state is read from HBM once and written once per launch).
+#pragma once
+#include <stdint.h>
+#include "atacom_envs.h"
+
+namespace atacom {
+
+constexpr int WAVE = 64;
+
+// ------------------------------------------------------------------ plane layout of the state buffer
+template <typename E>
+struct Planes {
+    static constexpr int Q = 0, DQ = Q + E::NQ, S = DQ + E::NQ, PUCK = S + E::NG, RHIT = PUCK + 6,
+                         VHX = RHIT + 1, IQ = VHX + 1, IDQ = IQ + E::NQ, IS = IDQ + E::NQ, IPUCK = IS + E::NG,
+                         SSUM = IPUCK + 6, SCMAX = SSUM + 1, SDQMAX = SCMAX + 1, COUNT = SDQMAX + 1;
+    static constexpr int I_HIT = 0, I_T = 1, I_CNT = 2, ICOUNT = 3;
+    static constexpr int STATE_DIM = 2 * E::NQ + E::NG + 6 + 4;
+    static constexpr int INIT_DIM = 2 * E::NQ + (E::PUCK ? 6 : 0);
+};
+
+template <typename T, typename E>
+struct EnvState {
+    T q[E::NQ], dq[E::NQ], s[E::NG], puck[6];
+    T r_hit, vel_hit_x;
+    int has_hit, t;
+};
+
+template <typename T>
+struct StepOut {
+    T reward;
+    bool absorbing, last;
+    T log_avg, log_max, log_dq;
+};
+
+template <typename T, typename E>
+__device__ __forceinline__ void load_state(const T* __restrict__ f, const int* __restrict__ ip, int B, int b,
+                                           EnvState<T, E>& st) {
+    using L = Planes<E>;
+#pragma unroll
+    for (int i = 0; i < E::NQ; ++i) { st.q[i] = f[(L::Q + i) * (size_t)B + b]; st.dq[i] = f[(L::DQ + i) * (size_t)B + b]; }
+#pragma unroll
+    for (int i = 0; i < E::NG; ++i) st.s[i] = f[(L::S + i) * (size_t)B + b];
+    if (E::PUCK) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) st.puck[i] = f[(L::PUCK + i) * (size_t)B + b];
+        st.r_hit = f[L::RHIT * (size_t)B + b];
+        st.vel_hit_x = f[L::VHX * (size_t)B + b];
+        st.has_hit = ip[L::I_HIT * (size_t)B + b];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) st.puck[i] = T(0);
+        st.r_hit = st.vel_hit_x = T(0);
+        st.has_hit = 0;
+    }
+    st.t = ip[L::I_T * (size_t)B + b];
+}
+
+template <typename T, typename E>
+__device__ __forceinline__ void store_state(T* __restrict__ f, int* __restrict__ ip, int B, int b,
+                                            const EnvState<T, E>& st) {
+    using L = Planes<E>;
+#pragma unroll
+    for (int i = 0; i < E::NQ; ++i) { f[(L::Q + i) * (size_t)B + b] = st.q[i]; f[(L::DQ + i) * (size_t)B + b] = st.dq[i]; }
+#pragma unroll
+    for (int i = 0; i < E::NG; ++i) f[(L::S + i) * (size_t)B + b] = st.s[i];
+    if (E::PUCK) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) f[(L::PUCK + i) * (size_t)B + b] = st.puck[i];
+        f[L::RHIT * (size_t)B + b] = st.r_hit;
+        f[L::VHX * (size_t)B + b] = st.vel_hit_x;
+        ip[L::I_HIT * (size_t)B + b] = st.has_hit;
+    }
+    ip[L::I_T * (size_t)B + b] = st.t;
+}
+
+template <typename T, typename E>
+__device__ __forceinline__ void load_init(const T* __restrict__ f, int B, int b, EnvState<T, E>& st) {
+    using L = Planes<E>;
+#pragma unroll
+    for (int i = 0; i < E::NQ; ++i) { st.q[i] = f[(L::IQ + i) * (size_t)B + b]; st.dq[i] = f[(L::IDQ + i) * (size_t)B + b]; }
+#pragma unroll
+    for (int i = 0; i < E::NG; ++i) st.s[i] = f[(L::IS + i) * (size_t)B + b];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) st.puck[i] = E::PUCK ? f[(L::IPUCK + i) * (size_t)B + b] : T(0);
+    st.r_hit = st.vel_hit_x = T(0);
+    st.has_hit = 0;
+    st.t = 0;
+}
+
+template <typename T, typename E>
+__device__ __forceinline__ void write_obs(const Params<T>& P, const EnvState<T, E>& st, T* __restrict__ o) {
+    if (E::ID == 0) {                                           // circle_base.py:83-84
+        o[0] = st.q[0]; o[1] = st.q[1]; o[2] = st.dq[0]; o[3] = st.dq[1];
+    } else {                                                    // env_single.py:82-120
+        o[0] = st.puck[0] - P.base_x; o[1] = st.puck[1] - P.base_y; o[2] = st.puck[2];
+        o[3] = st.puck[3]; o[4] = st.puck[4]; o[5] = st.puck[5];
+#pragma unroll
+        for (int i = 0; i < E::NQ; ++i) { o[6 + i] = st.q[i]; o[6 + E::NQ + i] = st.dq[i]; }
+    }
+}
+
+// slack initialisation, atacom.py:145-149
+template <typename T, typename E>
+__device__ __forceinline__ void slack_init(const Params<T>& P, EnvState<T, E>& st) {
+    T fun[E::NC], J[E::NC][E::NQ], bst[E::NC];
+    constraint_terms(E{}, P, st.q, st.dq, fun, J, bst);
+#pragma unroll
+    for (int g = 0; g < E::NG; ++g) {
+        const int r = E::NF + g;
+        T jdq = T(0);
+#pragma unroll
+        for (int i = 0; i < E::NQ; ++i) jdq = num<T>::fma(J[r][i], st.dq[i], jdq);
+        const T gv = num<T>::fma(P.K[r], jdq, fun[r]);
+        st.s[g] = num<T>::sqrt(num<T>::max(T(-2) * gv, T(0)));
+    }
+}
+
+// ------------------------------------------------------------------ one env step (A1, A2, A13-A15)
+template <typename T, typename E>
+__device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st, const T (&act)[E::NK],
+                                         StepOut<T>& out) {
+    constexpr int NQ = E::NQ, NF = E::NF, NG = E::NG, NC = E::NC, NN = E::NN, NK = E::NK;
+    T alpha[NK];
+    T anorm2 = T(0);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {                              // atacom.py:107-108
+        alpha[k] = num<T>::min(num<T>::max(act[k], T(-1)), T(1)) * P.alpha_max;
+        anorm2 = num<T>::fma(alpha[k], alpha[k], anorm2);
+    }
+    if (E::ID == 0) {                                           // circle_base.py:54,86-107 (logged BEFORE the step)
+        const T c1 = num<T>::abs(num<T>::fma(st.q[0], st.q[0], st.q[1] * st.q[1]) - T(1));
+        const T c2 = -st.q[1] - T(0.5);
+        out.log_avg = out.log_max = num<T>::max(c1, c2);
+        out.log_dq = num<T>::max(num<T>::abs(st.dq[0]), num<T>::abs(st.dq[1])) - T(1);
+    }
+    T qc[NQ], dqc[NQ];          // what the controller sees (held over the sub-steps when hold_q)
+    T A[NC][NQ], psi[NC], c0[NC];
+#pragma unroll 1
+    for (int sub = 0; sub < P.substeps; ++sub) {
+        if (sub == 0 || !P.hold_q) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) { qc[i] = st.q[i]; dqc[i] = st.dq[i]; }
+            T fun[NC], J[NC][NQ], bst[NC];
+            constraint_terms(E{}, P, qc, dqc, fun, J, bst);
+#pragma unroll
+            for (int r = 0; r < NC; ++r) {
+                T jdq = T(0);
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    jdq = num<T>::fma(J[r][i], dqc[i], jdq);
+                    const T kj = P.K[r] * J[r][i];              // constraints.py:39-40
+                    A[r][i] = (kj == T(0)) ? T(0) : kj;         // -0 -> +0 (the reference's matmul does the same)
+                }
+                psi[r] = num<T>::fma(P.K[r], bst[r], jdq);      // constraints.py:42-43
+                c0[r] = num<T>::fma(P.K[r], jdq, fun[r]);       // constraints.py:33-37
+            }
+        }
+        // J_c = [[K_f J_f, 0], [K_g J_g, diag(s)]],  rhs = psi + K_c c     (atacom.py:151-165,183-196)
+        T a[NC][NN], y[NC], x[NN], nb[NN][NK], nmu[NN];
+#pragma unroll
+        for (int r = 0; r < NC; ++r) {
+#pragma unroll
+            for (int c = 0; c < NQ; ++c) a[r][c] = A[r][c];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) a[r][NQ + g] = (r == NF + g) ? st.s[g] : T(0);
+            const T sv = (r >= NF) ? st.s[r >= NF ? r - NF : 0] : T(0);
+            const T cs = num<T>::fma(T(0.5) * sv, sv, c0[r]);       // c = fun + K J dq (+ s^2 / 2 on g rows)
+            y[r] = num<T>::fma(P.Kc[r], cs, psi[r]);
+        }
+        bidiag_solve_null<T, NC, NN>(a, y, x, nb);              // atacom.py:127 (pinv_null)
+        rref_apply<T, NN, NK>(nb, alpha, P.rref_tol, nmu);      // atacom.py:128,131
+#pragma unroll
+        for (int g = 0; g < NG; ++g) st.s[g] = num<T>::fma(nmu[NQ + g] - x[NQ + g], P.dt, st.s[g]);   // :135
+        T ddq[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {                          // acc_truncation, atacom.py:117-121
+            const T up = num<T>::max(num<T>::min(P.acc_max[i], -P.Kq[i] * (dqc[i] - P.vel_max[i])), -P.acc_max[i]);
+            const T lo = num<T>::min(num<T>::max(-P.acc_max[i], -P.Kq[i] * (dqc[i] + P.vel_max[i])), P.acc_max[i]);
+            ddq[i] = num<T>::min(num<T>::max(nmu[i] - x[i], lo), up);
+        }
+        if (E::ID == 0) {
+            // circle_atacom.py:26-27 + circle_base.py:59-63
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const T acc = num<T>::min(num<T>::max(ddq[i] / P.acc_max[i], T(-1)), T(1)) * T(10);
+                st.q[i] += num<T>::fma(st.dq[i], P.dt, acc * (P.dt * P.dt) / T(2));
+                st.dq[i] = num<T>::fma(acc, P.dt, st.dq[i]);
+            }
+        } else {
+            // dynamics model of this build: ID o FD = identity, semi-implicit Euler,
+            // velocity clamp at 1.5 x limit (iiwa_hit_atacom.py:48-50)
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const T vlim = T(1.5) * P.vel_max[i];
+                st.dq[i] = num<T>::min(num<T>::max(num<T>::fma(ddq[i], P.dt, st.dq[i]), -vlim), vlim);
+                st.q[i] = num<T>::fma(st.dq[i], P.dt, st.q[i]);
+            }
+            // puck: free motion; has_hit latch (env_hitting.py:80-85)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) st.puck[i] = num<T>::fma(st.puck[3 + i], P.dt, st.puck[i]);
+            const T pv2 = num<T>::fma(st.puck[3], st.puck[3], st.puck[4] * st.puck[4]);
+            const bool new_hit = (st.has_hit == 0) && (pv2 > T(0.01));
+            st.vel_hit_x = new_hit ? st.puck[3] : st.vel_hit_x;
+            st.has_hit = new_hit ? 1 : st.has_hit;
+        }
+    }
+    if (E::ID == 0) {
+        const T dx = T(1) - st.q[0];
+        out.reward = num<T>::exp(-num<T>::sqrt(num<T>::fma(dx, dx, st.q[1] * st.q[1])));   // circle_base.py:65
+        out.absorbing = false;                                                              // :67
+    } else {
+        T fun[NC], mxy[2];
+        constraint_fun(E{}, P, st.q, fun, mxy);
+        // absorbing: env_base.py:182-194 + env_hitting.py:71-78
+        const T pv2 = num<T>::fma(st.puck[3], st.puck[3], st.puck[4] * st.puck[4]);
+        bool ab = (num<T>::abs(st.puck[0]) > P.table_hx) || (num<T>::abs(st.puck[1]) > P.table_hy);
+        ab = ab || (num<T>::abs(mxy[0]) - P.table_hx > T(0.02)) || (num<T>::abs(mxy[1]) - P.table_hy > T(0.02));
+        ab = ab || ((st.has_hit != 0) && (pv2 < T(0.0001)));
+        // reward: env_hitting.py:39-69
+        const bool goal = (st.puck[0] - P.table_hx > T(0)) && (num<T>::abs(st.puck[1]) - P.goal_w < T(0));
+        const T dx = st.puck[0] - mxy[0], dy = st.puck[1] - mxy[1];
+        const T dist = num<T>::sqrt(num<T>::fma(dx, dx, dy * dy));
+        const T gx = P.goal_x - st.puck[0], gy = P.goal_y - st.puck[1];
+        const T gn = num<T>::sqrt(num<T>::fma(gx, gx, gy * gy));
+        T cosang = ((gx / gn) * (dx / dist)) + ((gy / gn) * (dy / dist));
+        cosang = num<T>::min(num<T>::max(cosang, T(0)), T(1));
+        const T r_app = num<T>::exp(T(-8) * (dist - T(0.08))) * cosang;
+        const bool upd = !ab && (st.has_hit == 0);
+        st.r_hit = upd ? r_app : st.r_hit;
+        T r = ab ? (goal ? T(80) : T(0)) : ((st.has_hit != 0) ? (T(1) + st.r_hit + st.vel_hit_x * T(0.1)) : r_app);
+        out.reward = r - P.action_penalty * num<T>::sqrt(anorm2);
+        out.absorbing = ab;
+        // constraint statistics, atacom.py:201-205
+        T cm = num<T>::abs(fun[0]);
+        if (NF == 0) cm = fun[0];
+#pragma unroll
+        for (int r2 = 1; r2 < NC; ++r2) cm = num<T>::max(cm, (r2 < NF) ? num<T>::abs(fun[r2]) : fun[r2]);
+        T dm = num<T>::abs(st.dq[0]) - P.vel_max[0];
+#pragma unroll
+        for (int i = 1; i < NQ; ++i) dm = num<T>::max(dm, num<T>::abs(st.dq[i]) - P.vel_max[i]);
+        out.log_avg = out.log_max = cm;
+        out.log_dq = dm;
+    }
+    st.t += 1;
+    out.last = out.absorbing || (st.t >= P.horizon);
+}
+
+// ------------------------------------------------------------------ kernels
+template <typename T, typename E>
+__global__ void __launch_bounds__(WAVE) k_step(const Params<T> P, T* __restrict__ f, int* __restrict__ ip,
+                                               const T* __restrict__ action, T* __restrict__ obs,
+                                               T* __restrict__ reward, uint8_t* __restrict__ absorbing,
+                                               uint8_t* __restrict__ last) {
+    using L = Planes<E>;
+    const int B = P.batch;
+    const int b = blockIdx.x * WAVE + threadIdx.x;
+    if (b >= B) return;
+    EnvState<T, E> st;
+    load_state<T, E>(f, ip, B, b, st);
+    T act[E::NK];
+#pragma unroll
+    for (int k = 0; k < E::NK; ++k) act[k] = action[(size_t)b * E::NK + k];
+    StepOut<T> out;
+    env_step<T, E>(P, st, act, out);
+    write_obs<T, E>(P, st, obs + (size_t)b * E::OBS);
+    reward[b] = out.reward;
+    absorbing[b] = out.absorbing ? 1 : 0;
+    if (last) last[b] = out.last ? 1 : 0;
+    f[L::SSUM * (size_t)B + b] += out.log_avg;
+    f[L::SCMAX * (size_t)B + b] = num<T>::max(f[L::SCMAX * (size_t)B + b], out.log_max);
+    f[L::SDQMAX * (size_t)B + b] = num<T>::max(f[L::SDQMAX * (size_t)B + b], out.log_dq);
+    ip[L::I_CNT * (size_t)B + b] += 1;
+    if (P.auto_reset && out.last) load_init<T, E>(f, B, b, st);
+    store_state<T, E>(f, ip, B, b, st);
+}
+
+template <typename T, typename E>
+__global__ void __launch_bounds__(WAVE) k_rollout(const Params<T> P, int n_steps, T* __restrict__ f,
+                                                  int* __restrict__ ip, const T* __restrict__ actions,
+                                                  T* __restrict__ obs, T* __restrict__ next_obs,
+                                                  T* __restrict__ reward, uint8_t* __restrict__ absorbing,
+                                                  uint8_t* __restrict__ last) {
+    using L = Planes<E>;
+    const int B = P.batch;
+    const int b = blockIdx.x * WAVE + threadIdx.x;
+    if (b >= B) return;
+    EnvState<T, E> st;
+    load_state<T, E>(f, ip, B, b, st);
+    T ssum = T(0), scmax = f[L::SCMAX * (size_t)B + b], sdq = f[L::SDQMAX * (size_t)B + b];
+#pragma unroll 1
+    for (int t = 0; t < n_steps; ++t) {
+        const size_t row = (size_t)t * B + b;
+        write_obs<T, E>(P, st, obs + row * E::OBS);
+        T act[E::NK];
+#pragma unroll
+        for (int k = 0; k < E::NK; ++k) act[k] = actions[row * E::NK + k];
+        StepOut<T> out;
+        env_step<T, E>(P, st, act, out);
+        if (next_obs) write_obs<T, E>(P, st, next_obs + row * E::OBS);
+        reward[row] = out.reward;
+        absorbing[row] = out.absorbing ? 1 : 0;
+        last[row] = out.last ? 1 : 0;
+        ssum += out.log_avg;
+        scmax = num<T>::max(scmax, out.log_max);
+        sdq = num<T>::max(sdq, out.log_dq);
+        if (P.auto_reset && out.last) load_init<T, E>(f, B, b, st);
+    }
+    f[L::SSUM * (size_t)B + b] += ssum;
+    f[L::SCMAX * (size_t)B + b] = scmax;
+    f[L::SDQMAX * (size_t)B + b] = sdq;
+    ip[L::I_CNT * (size_t)B + b] += n_steps;
+    store_state<T, E>(f, ip, B, b, st);
+}
+
+template <typename T, typename E>
+__global__ void __launch_bounds__(WAVE) k_reset(const Params<T> P, T* __restrict__ f, int* __restrict__ ip,
+                                                const uint8_t* __restrict__ mask, const T* __restrict__ init,
+                                                T* __restrict__ obs) {
+    using L = Planes<E>;
+    const int B = P.batch;
+    const int b = blockIdx.x * WAVE + threadIdx.x;
+    if (b >= B) return;
+    const bool m = mask ? (mask[b] != 0) : true;
+    EnvState<T, E> st;
+    if (m) {
+        if (init) {
+            const T* row = init + (size_t)b * L::INIT_DIM;
+#pragma unroll
+            for (int i = 0; i < E::NQ; ++i) {
+                f[(L::IQ + i) * (size_t)B + b] = row[i];
+                f[(L::IDQ + i) * (size_t)B + b] = row[E::NQ + i];
+            }
+            if (E::PUCK) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) f[(L::IPUCK + i) * (size_t)B + b] = row[2 * E::NQ + i];
+            }
+        }
+        load_init<T, E>(f, B, b, st);
+        slack_init<T, E>(P, st);
+#pragma unroll
+        for (int g = 0; g < E::NG; ++g) f[(L::IS + g) * (size_t)B + b] = st.s[g];
+        store_state<T, E>(f, ip, B, b, st);
+    } else {
+        load_state<T, E>(f, ip, B, b, st);
+    }
+    if (obs) write_obs<T, E>(P, st, obs + (size_t)b * E::OBS);
+}
+
+// set the stored initial state of every env to one row (used by create), clear statistics
+template <typename T, typename E>
+__global__ void k_fill_init(int B, T* __restrict__ f, int* __restrict__ ip, const T* __restrict__ row) {
+    using L = Planes<E>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+#pragma unroll
+    for (int i = 0; i < E::NQ; ++i) { f[(L::IQ + i) * (size_t)B + b] = row[i]; f[(L::IDQ + i) * (size_t)B + b] = row[E::NQ + i]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) f[(L::IPUCK + i) * (size_t)B + b] = row[2 * E::NQ + i];
+}
+
+template <typename T, typename E>
+__global__ void k_clear_stats(int B, T* __restrict__ f, int* __restrict__ ip) {
+    using L = Planes<E>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    f[L::SSUM * (size_t)B + b] = T(0);
+    f[L::SCMAX * (size_t)B + b] = -INFINITY;
+    f[L::SDQMAX * (size_t)B + b] = -INFINITY;
+    ip[L::I_CNT * (size_t)B + b] = 0;
+}
+
+// per-block partial reduction of the statistics: partial[block] = {sum, count, cmax, dqmax} (doubles)
+template <typename T, typename E>
+__global__ void __launch_bounds__(256) k_stats(int B, const T* __restrict__ f, const int* __restrict__ ip,
+                                               double* __restrict__ partial) {
+    using L = Planes<E>;
+    __shared__ double sh[4][256];
+    double s = 0.0, c = 0.0, m1 = -INFINITY, m2 = -INFINITY;
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
+        s += (double)f[L::SSUM * (size_t)B + b];
+        c += (double)ip[L::I_CNT * (size_t)B + b];
+        m1 = fmax(m1, (double)f[L::SCMAX * (size_t)B + b]);
+        m2 = fmax(m2, (double)f[L::SDQMAX * (size_t)B + b]);
+    }
+    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = c; sh[2][threadIdx.x] = m1; sh[3][threadIdx.x] = m2;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + w];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + w];
+            sh[2][threadIdx.x] = fmax(sh[2][threadIdx.x], sh[2][threadIdx.x + w]);
+            sh[3][threadIdx.x] = fmax(sh[3][threadIdx.x], sh[3][threadIdx.x + w]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 4 + 0] = sh[0][0];
+        partial[blockIdx.x * 4 + 1] = sh[1][0];
+        partial[blockIdx.x * 4 + 2] = sh[2][0];
+        partial[blockIdx.x * 4 + 3] = sh[3][0];
+    }
+}
+
+// state <-> user-facing array-of-structures [B, STATE_DIM] = [q, dq, s, puck(6), has_hit, r_hit, vel_hit_x, t]
+template <typename T, typename E>
+__global__ void k_get_state(int B, const T* __restrict__ f, const int* __restrict__ ip, T* __restrict__ out) {
+    using L = Planes<E>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    EnvState<T, E> st;
+    load_state<T, E>(f, ip, B, b, st);
+    if (E::PUCK == false) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) st.puck[i] = T(0);
+    }
+    T* o = out + (size_t)b * L::STATE_DIM;
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < E::NQ; ++i) o[k++] = st.q[i];
+#pragma unroll
+    for (int i = 0; i < E::NQ; ++i) o[k++] = st.dq[i];
+#pragma unroll
+    for (int i = 0; i < E::NG; ++i) o[k++] = st.s[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[k++] = st.puck[i];
+    o[k++] = (T)st.has_hit; o[k++] = st.r_hit; o[k++] = st.vel_hit_x; o[k++] = (T)st.t;
+}
+
+template <typename T, typename E>
+__global__ void k_set_state(int B, T* __restrict__ f, int* __restrict__ ip, const T* __restrict__ in) {
+    using L = Planes<E>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    EnvState<T, E> st;
+    const T* o = in + (size_t)b * L::STATE_DIM;
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < E::NQ; ++i) st.q[i] = o[k++];
+#pragma unroll
+    for (int i = 0; i < E::NQ; ++i) st.dq[i] = o[k++];
+#pragma unroll
+    for (int i = 0; i < E::NG; ++i) st.s[i] = o[k++];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) st.puck[i] = o[k++];
+    st.has_hit = (o[k++] != T(0)) ? 1 : 0; st.r_hit = o[k++]; st.vel_hit_x = o[k++]; st.t = (int)o[k++];
+    store_state<T, E>(f, ip, B, b, st);
+}
+
+// ------------------------------------------------------------------ stand-alone primitives (parity tests)
+template <typename T, typename E>
+__global__ void __launch_bounds__(WAVE) k_nullspace(int n, const T* __restrict__ Jc, const T* __restrict__ rhs,
+                                                    T tol, T* __restrict__ xo, T* __restrict__ nullo,
+                                                    T* __restrict__ rrefo) {
+    constexpr int NC = E::NC, NN = E::NN, NK = E::NK;
+    const int b = blockIdx.x * WAVE + threadIdx.x;
+    if (b >= n) return;
+    T a[NC][NN], y[NC], x[NN], nb[NN][NK];
+#pragma unroll
+    for (int r = 0; r < NC; ++r) {
+        y[r] = rhs ? rhs[(size_t)b * NC + r] : T(0);
+#pragma unroll
+        for (int c = 0; c < NN; ++c) a[r][c] = Jc[((size_t)b * NC + r) * NN + c];
+    }
+    bidiag_solve_null<T, NC, NN>(a, y, x, nb);
+    if (xo) {
+#pragma unroll
+        for (int c = 0; c < NN; ++c) xo[(size_t)b * NN + c] = x[c];
+    }
+    if (nullo) {
+#pragma unroll
+        for (int c = 0; c < NN; ++c)
+#pragma unroll
+            for (int k = 0; k < NK; ++k) nullo[((size_t)b * NN + c) * NK + k] = nb[c][k];
+    }
+    if (rrefo) {
+        // column k of rref(null) = rref_apply with alpha = e_k; the chart itself is computed once per k
+#pragma unroll 1
+        for (int k = 0; k < NK; ++k) {
+            T nb2[NN][NK], alpha[NK], col[NN];
+#pragma unroll
+            for (int c = 0; c < NN; ++c)
+#pragma unroll
+                for (int j = 0; j < NK; ++j) nb2[c][j] = nb[c][j];
+#pragma unroll
+            for (int j = 0; j < NK; ++j) alpha[j] = (j == k) ? T(1) : T(0);
+            rref_apply<T, NN, NK>(nb2, alpha, tol, col);
+#pragma unroll
+            for (int c = 0; c < NN; ++c) rrefo[((size_t)b * NN + c) * NK + k] = col[c];
+        }
+    }
+}
+
+template <typename T, typename E>
+__global__ void __launch_bounds__(WAVE) k_terms(const Params<T> P, int n, const T* __restrict__ q,
+                                                const T* __restrict__ dq, T* __restrict__ fun_o,
+                                                T* __restrict__ J_o, T* __restrict__ b_o) {
+    const int b = blockIdx.x * WAVE + threadIdx.x;
+    if (b >= n) return;
+    T qq[E::NQ], dd[E::NQ], fun[E::NC], J[E::NC][E::NQ], bst[E::NC];
+#pragma unroll
+    for (int i = 0; i < E::NQ; ++i) { qq[i] = q[(size_t)b * E::NQ + i]; dd[i] = dq[(size_t)b * E::NQ + i]; }
+    constraint_terms(E{}, P, qq, dd, fun, J, bst);
+#pragma unroll
+    for (int r = 0; r < E::NC; ++r) {
+        fun_o[(size_t)b * E::NC + r] = fun[r];
+        b_o[(size_t)b * E::NC + r] = bst[r];
+#pragma unroll
+        for (int i = 0; i < E::NQ; ++i) J_o[((size_t)b * E::NC + r) * E::NQ + i] = J[r][i];
+    }
+}
+
+}  // namespace atacom

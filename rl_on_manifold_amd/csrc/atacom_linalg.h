@@ -1,0 +1,236 @@
+// Per-environment small dense linear algebra for the ATACOM tangent-space map, one environment per
+// lane, every matrix held in VGPRs (all loops have compile-time trip counts and are fully unrolled so
+// that no array is ever indexed dynamically).
+//
+// What it replaces in the reference (float64 numpy/scipy on the host, one call per env per sub-step):
+//   * pinv_null  -- /root/reference/atacom/utils/null_space_coordinate.py:8-26  (LAPACK dgesdd SVD)
+//   * rref       -- /root/reference/atacom/utils/null_space_coordinate.py:40-79 (tol = 0.05,
+//                   /root/reference/atacom/atacom.py:128)
+//
+// Algorithm (DESIGN.md "Null-space numerics"): the reference's orthonormal null basis is whatever
+// LAPACK's dgesdd returns, and the tolerance test inside rref looks at basis-dependent entries, so to
+// reproduce the reference in the chart-switching regime the kernel has to produce the *same* basis.
+// For an M x N matrix with M < N < 11M/6 dgesdd bidiagonalises A = Q B P^T with Householder
+// reflectors (dgebd2/dlarfg) and returns vh[M:] = last N-M columns of P = G(1)...G(M).  We therefore
+// run the same Golub-Kahan Householder bidiagonalisation per lane -- no SVD iteration is needed: the
+// null basis is P[:, M:], and the pseudo-inverse solve is  x = P [B^{-1} Q^T r ; 0]  with B lower
+// bidiagonal.  MFMA is deliberately not used: every lane owns a different 12x17 matrix and the work
+// is a dependent chain of rank-1 updates, not a shared-operand contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace atacom {
+
+template <typename T> struct num;
+template <> struct num<float> {
+    static __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
+    static __device__ __forceinline__ float abs(float x) { return __builtin_fabsf(x); }
+    static __device__ __forceinline__ float copysign(float m, float s) { return __builtin_copysignf(m, s); }
+    static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+    static __device__ __forceinline__ float exp(float x) { return expf(x); }
+    static __device__ __forceinline__ void sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+    static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
+    static __device__ __forceinline__ float min(float a, float b) { return fminf(a, b); }
+};
+template <> struct num<double> {
+    static __device__ __forceinline__ double sqrt(double x) { return __builtin_sqrt(x); }
+    static __device__ __forceinline__ double abs(double x) { return __builtin_fabs(x); }
+    static __device__ __forceinline__ double copysign(double m, double s) { return __builtin_copysign(m, s); }
+    static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+    static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+    static __device__ __forceinline__ void sincos(double x, double* s, double* c) { ::sincos(x, s, c); }
+    static __device__ __forceinline__ double max(double a, double b) { return fmax(a, b); }
+    static __device__ __forceinline__ double min(double a, double b) { return fmin(a, b); }
+};
+
+// LAPACK dlarfg on (alpha, x[0..L)) given ss = sum x^2: H = I - tau [1;v][1;v]^T, H [alpha;x] = [beta;0].
+// Returns the scale 1/(alpha-beta) to apply to x (0 when x == 0, i.e. H = I), writes beta and tau.
+template <typename T>
+__device__ __forceinline__ T larfg_scale(T alpha, T ss, T& beta, T& tau) {
+    const bool nz = ss != T(0);
+    const T nrm = num<T>::sqrt(num<T>::fma(alpha, alpha, ss));
+    const T b = -num<T>::copysign(nrm, alpha);
+    beta = nz ? b : alpha;
+    const T safe_b = nz ? b : T(1);
+    tau = nz ? (b - alpha) / safe_b : T(0);
+    const T den = nz ? (alpha - b) : T(1);
+    return nz ? T(1) / den : T(0);
+}
+
+// a: M x N (row i, col j), full row rank; y: right-hand side (length M).
+// On return  x = a^+ y  (length N)  and  nb = orthonormal null basis (N x K, K = N - M), equal to
+// scipy.linalg.svd(a, full_matrices=True)[2][M:].T up to rounding.  a and y are destroyed.
+template <typename T, int M, int N>
+__device__ __forceinline__ void bidiag_solve_null(T (&a)[M][N], T (&y)[M], T (&x)[N], T (&nb)[N][N - M]) {
+    constexpr int K = N - M;
+    T d[M], e[M], taup[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        // ---- right reflector G(i): annihilate a[i][i+1..N)
+        T ss = T(0);
+#pragma unroll
+        for (int c = i + 1; c < N; ++c) ss = num<T>::fma(a[i][c], a[i][c], ss);
+        T beta, tp;
+        const T sc = larfg_scale(a[i][i], ss, beta, tp);
+        d[i] = beta;
+        taup[i] = tp;
+#pragma unroll
+        for (int c = i + 1; c < N; ++c) a[i][c] *= sc;          // v (v[i] = 1 implicit) kept in place
+        if (i < M - 1) {
+            // apply G(i) from the right to rows i+1..M-1
+#pragma unroll
+            for (int r = i + 1; r < M; ++r) {
+                T w = a[r][i];
+#pragma unroll
+                for (int c = i + 1; c < N; ++c) w = num<T>::fma(a[r][c], a[i][c], w);
+                w *= tp;
+                a[r][i] -= w;
+#pragma unroll
+                for (int c = i + 1; c < N; ++c) a[r][c] = num<T>::fma(-w, a[i][c], a[r][c]);
+            }
+            // ---- left reflector H(i): annihilate a[i+2..M)[i]
+            T su = T(0);
+#pragma unroll
+            for (int r = i + 2; r < M; ++r) su = num<T>::fma(a[r][i], a[r][i], su);
+            T betaq, tq;
+            const T scq = larfg_scale(a[i + 1][i], su, betaq, tq);
+            e[i] = betaq;
+#pragma unroll
+            for (int r = i + 2; r < M; ++r) a[r][i] *= scq;      // u (u[i+1] = 1 implicit)
+#pragma unroll
+            for (int c = i + 1; c < N; ++c) {
+                T w = a[i + 1][c];
+#pragma unroll
+                for (int r = i + 2; r < M; ++r) w = num<T>::fma(a[r][i], a[r][c], w);
+                w *= tq;
+                a[i + 1][c] -= w;
+#pragma unroll
+                for (int r = i + 2; r < M; ++r) a[r][c] = num<T>::fma(-w, a[r][i], a[r][c]);
+            }
+            {   // the same H(i) on the right-hand side: y <- Q^T y
+                T w = y[i + 1];
+#pragma unroll
+                for (int r = i + 2; r < M; ++r) w = num<T>::fma(a[r][i], y[r], w);
+                w *= tq;
+                y[i + 1] -= w;
+#pragma unroll
+                for (int r = i + 2; r < M; ++r) y[r] = num<T>::fma(-w, a[r][i], y[r]);
+            }
+        }
+    }
+    // ---- z = B^{-1} (Q^T y), B lower bidiagonal (d on the diagonal, e below it)
+    x[0] = y[0] / d[0];
+#pragma unroll
+    for (int i = 1; i < M; ++i) x[i] = num<T>::fma(-e[i - 1], x[i - 1], y[i]) / d[i];
+#pragma unroll
+    for (int c = M; c < N; ++c) x[c] = T(0);
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+#pragma unroll
+        for (int k = 0; k < K; ++k) nb[r][k] = (r == M + k) ? T(1) : T(0);
+    // ---- [x | nb] <- G(1) ... G(M) [x | nb]
+#pragma unroll
+    for (int i = M - 1; i >= 0; --i) {
+        {
+            T w = x[i];
+#pragma unroll
+            for (int c = i + 1; c < N; ++c) w = num<T>::fma(a[i][c], x[c], w);
+            w *= taup[i];
+            x[i] -= w;
+#pragma unroll
+            for (int c = i + 1; c < N; ++c) x[c] = num<T>::fma(-w, a[i][c], x[c]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            T w = nb[i][k];
+#pragma unroll
+            for (int c = i + 1; c < N; ++c) w = num<T>::fma(a[i][c], nb[c][k], w);
+            w *= taup[i];
+            nb[i][k] -= w;
+#pragma unroll
+            for (int c = i + 1; c < N; ++c) nb[c][k] = num<T>::fma(-w, a[i][c], nb[c][k]);
+        }
+    }
+}
+
+// Gauss-Jordan "chart" of the null basis with the reference's pivot tolerance
+// (null_space_coordinate.py:40-79 called with row_vectors=False, tol): operates on V = nb^T (K x N).
+// Branch-free per lane; rows are not physically swapped -- instead each row remembers the order in
+// which it became a pivot row (order[r] in 0..K-1, or -1), which is the row index it would occupy
+// after the reference's swaps.  Returns mu_null[n] = sum_r alpha[order[r]] * V[r][n] = (Nc @ alpha)[n].
+template <typename T, int N, int K>
+__device__ __forceinline__ void rref_apply(T (&nb)[N][K], const T (&alpha)[K], T tol, T (&out)[N]) {
+    int order[K];
+    bool used[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) { order[r] = -1; used[r] = false; }
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const bool active = cnt < K;
+        if (__builtin_amdgcn_ballot_w64(active) != 0ull) {      // wave-uniform early-out
+            T p = T(-1);
+            int kk = 0;
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                const T av = used[r] ? T(-1) : num<T>::abs(nb[j][r]);
+                const bool gt = av > p;                          // strict: keeps the first maximum
+                p = gt ? av : p;
+                kk = gt ? r : kk;
+            }
+            const bool piv = active && (p > tol);
+            const bool skip = active && !piv;
+            // pivot value and reciprocal (0 on lanes that do not pivot, so they are left untouched)
+            T pj = T(0);
+#pragma unroll
+            for (int r = 0; r < K; ++r) pj = (r == kk) ? nb[j][r] : pj;
+            const T inv = piv ? T(1) / pj : T(0);
+            T f[K];
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                const bool is_p = piv && (r == kk);
+                f[r] = (piv && !is_p) ? nb[j][r] : T(0);
+                // column j itself: pivot row -> 1, other rows -> 0 (exactly), skipped -> 0 on unused rows
+                const T cur = nb[j][r];
+                nb[j][r] = is_p ? T(1) : ((piv || (skip && !used[r])) ? T(0) : cur);
+            }
+#pragma unroll
+            for (int c = j + 1; c < N; ++c) {
+                T pr = T(0);
+#pragma unroll
+                for (int r = 0; r < K; ++r) pr = (r == kk) ? nb[c][r] : pr;
+                pr *= inv;
+#pragma unroll
+                for (int r = 0; r < K; ++r) {
+                    const bool is_p = piv && (r == kk);
+                    const T upd = num<T>::fma(-f[r], pr, nb[c][r]);
+                    nb[c][r] = is_p ? pr : upd;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < K; ++r) {
+                const bool is_p = piv && (r == kk);
+                order[r] = is_p ? cnt : order[r];
+                used[r] = used[r] || is_p;
+            }
+            cnt += piv ? 1 : 0;
+        }
+    }
+    T ar[K];
+#pragma unroll
+    for (int r = 0; r < K; ++r) {
+        T v = T(0);
+#pragma unroll
+        for (int k = 0; k < K; ++k) v = (order[r] == k) ? alpha[k] : v;
+        ar[r] = v;
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        T v = T(0);
+#pragma unroll
+        for (int r = 0; r < K; ++r) v = num<T>::fma(ar[r], nb[n][r], v);
+        out[n] = v;
+    }
+}
+
+}  // namespace atacom

@@ -1,0 +1,91 @@
+// Instantiates the kernels of atacom_kernels.h for one environment and fills its EnvOps tables.
+#pragma once
+#include "atacom_kernels.h"
+#include "atacom_ops.h"
+
+namespace atacom {
+
+template <typename T>
+static Params<T> make_params(const atacom_config& c) {
+    Params<T> P;
+    P.batch = c.batch; P.substeps = c.substeps; P.horizon = c.horizon; P.hold_q = c.hold_q;
+    P.bias_mode = c.bias_mode; P.auto_reset = c.auto_reset;
+    P.dt = (T)c.dt; P.rref_tol = (T)c.rref_tol; P.action_penalty = (T)c.action_penalty;
+    double amax = c.acc_max[0];
+    for (int i = 0; i < ATACOM_MAX_C; ++i) { P.K[i] = (T)c.K[i]; P.Kc[i] = (T)c.Kc[i]; }
+    for (int i = 0; i < ATACOM_MAX_Q; ++i) {
+        P.vel_max[i] = (T)c.vel_max[i]; P.acc_max[i] = (T)c.acc_max[i]; P.Kq[i] = (T)c.Kq[i];
+        P.pos_limit[i] = (T)c.pos_limit[i];
+    }
+    const int nq = c.env_id == ATACOM_ENV_CIRCLE ? 2 : (c.env_id == ATACOM_ENV_PLANAR ? 3 : 6);
+    for (int i = 1; i < nq; ++i) amax = c.acc_max[i] > amax ? c.acc_max[i] : amax;
+    P.alpha_max = (T)amax;                       // atacom.py:71
+    P.base_x = (T)c.base_xy[0]; P.base_y = (T)c.base_xy[1];
+    for (int i = 0; i < 3; ++i) P.link[i] = (T)c.link[i];
+    // env_base.py:155-159, env_hitting.py:11-12, iiwa_hit_atacom.py:104-105
+    const double table_l = 1.96, table_w = 1.02, mallet_r = 0.05;
+    P.table_bx = (T)(table_l / 2 - mallet_r); P.table_by = (T)(table_w / 2 - mallet_r);
+    P.table_hx = (T)(table_l / 2); P.table_hy = (T)(table_w / 2);
+    P.goal_x = (T)0.98; P.goal_y = (T)0.0; P.goal_w = (T)0.25;
+    P.ee_height = (T)0.1505; P.z4_min = (T)0.36; P.z7_min = (T)0.25;
+    return P;
+}
+
+static inline int nblk(int n, int per) { return (n + per - 1) / per; }
+
+template <typename T, typename E>
+struct Ops {
+    using L = Planes<E>;
+    static void step(const atacom_config& c, void* f, int* ip, const void* act, void* obs, void* rew, uint8_t* ab,
+                     uint8_t* last, hipStream_t s) {
+        hipLaunchKernelGGL((k_step<T, E>), dim3(nblk(c.batch, WAVE)), dim3(WAVE), 0, s, make_params<T>(c), (T*)f, ip,
+                           (const T*)act, (T*)obs, (T*)rew, ab, last);
+    }
+    static void rollout(const atacom_config& c, int n_steps, void* f, int* ip, const void* acts, void* obs,
+                        void* nobs, void* rew, uint8_t* ab, uint8_t* last, hipStream_t s) {
+        hipLaunchKernelGGL((k_rollout<T, E>), dim3(nblk(c.batch, WAVE)), dim3(WAVE), 0, s, make_params<T>(c),
+                           n_steps, (T*)f, ip, (const T*)acts, (T*)obs, (T*)nobs, (T*)rew, ab, last);
+    }
+    static void reset(const atacom_config& c, void* f, int* ip, const uint8_t* mask, const void* init, void* obs,
+                      hipStream_t s) {
+        hipLaunchKernelGGL((k_reset<T, E>), dim3(nblk(c.batch, WAVE)), dim3(WAVE), 0, s, make_params<T>(c), (T*)f, ip,
+                           mask, (const T*)init, (T*)obs);
+    }
+    static void fill_init(const atacom_config& c, void* f, int* ip, const void* row, hipStream_t s) {
+        hipLaunchKernelGGL((k_fill_init<T, E>), dim3(nblk(c.batch, 256)), dim3(256), 0, s, c.batch, (T*)f, ip,
+                           (const T*)row);
+    }
+    static void clear_stats(const atacom_config& c, void* f, int* ip, hipStream_t s) {
+        hipLaunchKernelGGL((k_clear_stats<T, E>), dim3(nblk(c.batch, 256)), dim3(256), 0, s, c.batch, (T*)f, ip);
+    }
+    static void stats(const atacom_config& c, const void* f, const int* ip, double* partial, int nblocks,
+                      hipStream_t s) {
+        hipLaunchKernelGGL((k_stats<T, E>), dim3(nblocks), dim3(256), 0, s, c.batch, (const T*)f, ip, partial);
+    }
+    static void get_state(const atacom_config& c, const void* f, const int* ip, void* out, hipStream_t s) {
+        hipLaunchKernelGGL((k_get_state<T, E>), dim3(nblk(c.batch, 256)), dim3(256), 0, s, c.batch, (const T*)f, ip,
+                           (T*)out);
+    }
+    static void set_state(const atacom_config& c, void* f, int* ip, const void* in, hipStream_t s) {
+        hipLaunchKernelGGL((k_set_state<T, E>), dim3(nblk(c.batch, 256)), dim3(256), 0, s, c.batch, (T*)f, ip,
+                           (const T*)in);
+    }
+    static void nullspace(int n, const void* Jc, const void* rhs, double tol, void* x, void* nullb, void* rref,
+                          hipStream_t s) {
+        hipLaunchKernelGGL((k_nullspace<T, E>), dim3(nblk(n, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,
+                           (const T*)rhs, (T)tol, (T*)x, (T*)nullb, (T*)rref);
+    }
+    static void terms(const atacom_config& c, int n, const void* q, const void* dq, void* fun, void* J, void* b,
+                      hipStream_t s) {
+        hipLaunchKernelGGL((k_terms<T, E>), dim3(nblk(n, WAVE)), dim3(WAVE), 0, s, make_params<T>(c), n,
+                           (const T*)q, (const T*)dq, (T*)fun, (T*)J, (T*)b);
+    }
+    static const EnvOps* table() {
+        static const EnvOps ops = {L::COUNT, L::ICOUNT, L::STATE_DIM, L::INIT_DIM, E::OBS, E::NQ, E::NF, E::NG, E::NK,
+                                   sizeof(T), &step, &rollout, &reset, &fill_init, &clear_stats, &stats,
+                                   &get_state, &set_state, &nullspace, &terms};
+        return &ops;
+    }
+};
+
+}  // namespace atacom

@@ -1,0 +1,217 @@
+"""Batched ATACOM environments on one MI355X: the host-side mirror of the reference's
+`AtacomEnvWrapper` surface (/root/reference/atacom/atacom.py:90-115,141-143,207-216) with a leading
+batch dimension.  All arithmetic happens in libatacom_hip.so (hand-written HIP, gfx950); this file
+only moves pointers: torch ROCm tensors supply device memory and the current HIP stream.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .spaces import Box, MDPInfo
+
+_ENV_IDS = {'circle': _lib.ENV_CIRCLE, 'A': _lib.ENV_CIRCLE, 'planar': _lib.ENV_PLANAR, 'H': _lib.ENV_PLANAR,
+            'iiwa': _lib.ENV_IIWA, '7H': _lib.ENV_IIWA}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class BatchedAtacomEnv:
+    """`batch` independent ATACOM environments stepped by one HIP kernel launch per call.
+
+    Same method names as the reference wrapper, batched:
+      reset(mask=None, state=None) -> obs[B, D]
+      step(actions[B, k])          -> obs[B, D], reward[B], absorbing[B] (bool), {'last': bool[B]}
+      rollout(actions[T, B, k])    -> dict of time-major tensors, T steps in ONE launch
+      get_constraints_logs()       -> (c_avg, c_max, c_dq_max), clears the log   (atacom.py:207-216)
+    Tensors are torch tensors on `device` (zero-copy); numpy inputs are accepted and copied.
+    """
+
+    def __init__(self, env, batch, device='cuda:0', dtype=torch.float32, horizon=None, gamma=None, Kc=None,
+                 time_step=None, n_intermediate_steps=None, action_penalty=None, auto_reset=False,
+                 hold_q=None, bias_mode='reference', rref_tol=None):
+        lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.AtacomError("BatchedAtacomEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                   "there is no CPU fallback")
+        self.env_id = _ENV_IDS[env] if isinstance(env, str) else int(env)
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.AtacomError("device must be a ROCm GPU ('cuda:N')")
+        self.dtype = dtype
+        cfg = _lib.default_config(self.env_id)
+        cfg.batch = int(batch)
+        cfg.dtype = {torch.float32: _lib.F32, torch.float64: _lib.F64}[dtype]
+        if horizon is not None:
+            cfg.horizon = int(horizon)
+        if gamma is not None:
+            cfg.gamma = float(gamma)
+        if time_step is not None:
+            cfg.dt = float(time_step)
+        if n_intermediate_steps is not None:
+            cfg.substeps = int(n_intermediate_steps)
+        if action_penalty is not None:
+            cfg.action_penalty = float(action_penalty)
+        if rref_tol is not None:
+            cfg.rref_tol = float(rref_tol)
+        if hold_q is not None:
+            cfg.hold_q = int(bool(hold_q))
+        cfg.bias_mode = {'reference': 0, 'exact': 1}[bias_mode]
+        cfg.auto_reset = int(bool(auto_reset))
+        d = _lib.get_dims(self.env_id)
+        self.dims = {'q': d.dim_q, 'f': d.n_f, 'g': d.n_g, 'null': d.n_null, 'c': d.n_f + d.n_g}   # atacom.py:25-40
+        self.obs_dim, self.state_dim, self.init_state_dim = d.obs_dim, d.state_dim, d.init_state_dim
+        if Kc is not None:
+            kc = np.broadcast_to(np.asarray(Kc, dtype=np.float64), (self.dims['c'],))
+            for i in range(self.dims['c']):
+                cfg.Kc[i] = float(kc[i])
+        self.cfg = cfg
+        self.batch = int(batch)
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        h = C.c_void_p()
+        _lib.check(lib.atacom_create(C.byref(cfg), self._dev_index, C.byref(h)))
+        self._h = h
+        self._lib = lib
+        B, k, D = self.batch, self.dims['null'], self.obs_dim
+        self._obs = torch.empty((B, D), device=self.device, dtype=dtype)
+        self._reward = torch.empty((B,), device=self.device, dtype=dtype)
+        self._absorbing = torch.empty((B,), device=self.device, dtype=torch.uint8)
+        self._last = torch.empty((B,), device=self.device, dtype=torch.uint8)
+        inf = np.full(D, np.inf)
+        self._mdp_info = MDPInfo(Box(-inf, inf), Box(-np.ones(k), np.ones(k)), cfg.gamma, cfg.horizon)   # atacom.py:50-51
+        self.reset()
+
+    # ------------------------------------------------------------------ reference surface
+    @property
+    def info(self):
+        return self._mdp_info
+
+    def seed(self, seed):
+        """Kept for API parity (atacom.py:90-91); the device path is deterministic and draws no random numbers."""
+        self._seed = seed
+
+    def render(self):
+        pass
+
+    def stop(self):
+        pass
+
+    def set_logger(self, logger):
+        self._logger = logger
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _as_dev(self, x, shape, dtype=None):
+        t = torch.as_tensor(x, dtype=dtype or self.dtype, device=self.device)
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(t.shape)))
+        return t.contiguous()
+
+    def reset(self, mask=None, state=None):
+        """Reset the masked envs (all if mask is None).  `state` ([B, init_state_dim] = [q, dq(, puck6)]) replaces
+        their stored initial state first.  Returns the observation of every env."""
+        m = None if mask is None else self._as_dev(mask, (self.batch,), torch.uint8)
+        s = None if state is None else self._as_dev(state, (self.batch, self.init_state_dim))
+        _lib.check(self._lib.atacom_reset(self._h, _ptr(m), _ptr(s), _ptr(self._obs), self._stream()))
+        return self._obs.clone()
+
+    def step(self, actions):
+        a = self._as_dev(actions, (self.batch, self.dims['null']))
+        _lib.check(self._lib.atacom_step(self._h, _ptr(a), _ptr(self._obs), _ptr(self._reward),
+                                          _ptr(self._absorbing), _ptr(self._last), self._stream()))
+        return self._obs.clone(), self._reward.clone(), self._absorbing.bool(), {'last': self._last.bool()}
+
+    def step_into(self, actions, obs, reward, absorbing, last=None):
+        """Allocation-free variant of step(): caller-owned output tensors (uint8 for the flags)."""
+        _lib.check(self._lib.atacom_step(self._h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(absorbing),
+                                          _ptr(last), self._stream()))
+
+    def rollout(self, actions, want_next_obs=True, out=None):
+        """T env steps in one kernel launch.  actions [T, B, k] -> dict(obs, next_obs, reward, absorbing, last)."""
+        T = int(actions.shape[0])
+        a = self._as_dev(actions, (T, self.batch, self.dims['null']))
+        B, D = self.batch, self.obs_dim
+        if out is None:
+            out = {'obs': torch.empty((T, B, D), device=self.device, dtype=self.dtype),
+                   'next_obs': torch.empty((T, B, D), device=self.device, dtype=self.dtype) if want_next_obs else None,
+                   'reward': torch.empty((T, B), device=self.device, dtype=self.dtype),
+                   'absorbing': torch.empty((T, B), device=self.device, dtype=torch.uint8),
+                   'last': torch.empty((T, B), device=self.device, dtype=torch.uint8)}
+        _lib.check(self._lib.atacom_rollout(self._h, T, _ptr(a), _ptr(out['obs']), _ptr(out.get('next_obs')),
+                                             _ptr(out['reward']), _ptr(out['absorbing']), _ptr(out['last']),
+                                             self._stream()))
+        out['action'] = a
+        return out
+
+    def get_constraints_logs(self, clear=True):
+        res = (C.c_double * 3)()
+        _lib.check(self._lib.atacom_get_stats(self._h, C.byref(res), int(clear), self._stream()))
+        return float(res[0]), float(res[1]), float(res[2])
+
+    # ------------------------------------------------------------------ state injection / checkpoint
+    def get_state(self):
+        """[B, state_dim] = [q, dq, s, puck(6), has_hit, r_hit, vel_hit_x, t]."""
+        st = torch.empty((self.batch, self.state_dim), device=self.device, dtype=self.dtype)
+        _lib.check(self._lib.atacom_get_state(self._h, _ptr(st), self._stream()))
+        return st
+
+    def set_state(self, state):
+        st = self._as_dev(state, (self.batch, self.state_dim))
+        _lib.check(self._lib.atacom_set_state(self._h, _ptr(st), self._stream()))
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self._lib.atacom_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+# ---------------------------------------------------------------------- stand-alone primitives
+def nullspace(env, Jc, rhs=None, tol=0.05):
+    """Batched pinv_null + rref on the GPU (null_space_coordinate.py:8-26,40-79).
+    Jc [n, c, c+k] (torch, on a ROCm device).  Returns (x = Jc^+ rhs, null basis, rref(null, tol))."""
+    lib = _lib.load()
+    env_id = _ENV_IDS[env] if isinstance(env, str) else int(env)
+    d = _lib.get_dims(env_id)
+    c, k = d.n_f + d.n_g, d.n_null
+    n = Jc.shape[0]
+    assert Jc.is_cuda and tuple(Jc.shape) == (n, c, c + k)
+    Jc = Jc.contiguous()
+    dt = {torch.float32: _lib.F32, torch.float64: _lib.F64}[Jc.dtype]
+    rhs = torch.zeros((n, c), device=Jc.device, dtype=Jc.dtype) if rhs is None else rhs.contiguous()
+    x = torch.empty((n, c + k), device=Jc.device, dtype=Jc.dtype)
+    nb = torch.empty((n, c + k, k), device=Jc.device, dtype=Jc.dtype)
+    rr = torch.empty((n, c + k, k), device=Jc.device, dtype=Jc.dtype)
+    stream = C.c_void_p(torch.cuda.current_stream(Jc.device).cuda_stream)
+    with torch.cuda.device(Jc.device):
+        _lib.check(lib.atacom_nullspace(env_id, dt, n, _ptr(Jc), _ptr(rhs), float(tol), _ptr(x), _ptr(nb), _ptr(rr),
+                                        stream))
+    return x, nb, rr
+
+
+def constraint_terms(env, q, dq, bias_mode='reference'):
+    """fun / J / b callables of an environment evaluated on the GPU for q, dq [n, dim_q]."""
+    lib = _lib.load()
+    env_id = _ENV_IDS[env] if isinstance(env, str) else int(env)
+    d = _lib.get_dims(env_id)
+    cfg = _lib.default_config(env_id)
+    cfg.dtype = {torch.float32: _lib.F32, torch.float64: _lib.F64}[q.dtype]
+    cfg.bias_mode = {'reference': 0, 'exact': 1}[bias_mode]
+    n, c = q.shape[0], d.n_f + d.n_g
+    q, dq = q.contiguous(), dq.contiguous()
+    fun = torch.empty((n, c), device=q.device, dtype=q.dtype)
+    J = torch.empty((n, c, d.dim_q), device=q.device, dtype=q.dtype)
+    b = torch.empty((n, c), device=q.device, dtype=q.dtype)
+    stream = C.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+    with torch.cuda.device(q.device):
+        _lib.check(lib.atacom_constraint_terms(C.byref(cfg), n, _ptr(q), _ptr(dq), _ptr(fun), _ptr(J), _ptr(b), stream))
+    return fun, J, b

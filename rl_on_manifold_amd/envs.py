@@ -1,0 +1,131 @@
+"""Batch-1 facades with the reference's constructor signatures and numpy in / numpy out, so that existing
+MushroomRL-style scripts (examples/*_exp.py: `mdp.info`, `mdp.reset()`, `mdp.step(a)`,
+`mdp.get_constraints_logs()`) run unchanged on the HIP engine:
+
+  CircleEnvAtacom        /root/reference/atacom/environments/circular_motion/circle_atacom.py:6-18
+  AirHockeyPlanarAtacom  /root/reference/atacom/environments/planar_air_hockey/atacom_air_hockey.py:11-14
+  AirHockeyIiwaAtacom    /root/reference/atacom/environments/iiwa_air_hockey/iiwa_hit_atacom.py:10-13
+
+They are thin: one BatchedAtacomEnv with batch = 1 (or `n_envs` > 1 for a vectorised agent).
+"""
+import numpy as np
+import torch
+
+from .engine import BatchedAtacomEnv
+
+HIT_RANGE = np.array([[-0.6, -0.2], [-0.4, 0.4]])      # env_hitting.py:11
+
+
+class _Facade:
+    _env_name = None
+
+    def _make(self, **kw):
+        self._engine = BatchedAtacomEnv(self._env_name, batch=1, **kw)
+        self.dims = self._engine.dims
+        self.state = self._engine.reset()[0].cpu().numpy().astype(np.float64)
+
+    @property
+    def info(self):
+        return self._engine.info
+
+    def seed(self, seed):
+        np.random.seed(seed)          # the reference's random_init draws from numpy's global generator
+        self._engine.seed(seed)
+
+    def render(self):
+        pass
+
+    def stop(self):
+        self._engine.stop()
+
+    def set_logger(self, logger):
+        self._engine.set_logger(logger)
+
+    def step(self, action):
+        """atacom.py:106-115: returns (state copy, float reward, bool absorbing, {})."""
+        a = np.asarray(action, dtype=np.float64).reshape(1, -1)
+        obs, r, ab, _ = self._engine.step(a)
+        self.state = obs[0].cpu().numpy().astype(np.float64)
+        return self.state.copy(), float(r[0].item()), bool(ab[0].item()), {}
+
+    def get_constraints_logs(self):
+        return self._engine.get_constraints_logs()
+
+
+class CircleEnvAtacom(_Facade):
+    _env_name = 'circle'
+
+    def __init__(self, horizon=500, gamma=0.99, random_init=False, Kc=100, time_step=0.01, device='cuda:0',
+                 dtype=torch.float32):
+        self.random_init = random_init
+        self._make(horizon=horizon, gamma=gamma, Kc=Kc, time_step=time_step, device=device, dtype=dtype)
+
+    def reset(self, state=None):
+        if state is None:
+            if self.random_init:                       # circle_base.py:36-42
+                y = np.random.uniform(-0.5, 1)
+                x = np.sqrt(1 - y ** 2) * np.sign(np.random.uniform(-1, 1))
+                dx = np.random.uniform(-1, 1)
+                dy = -x * dx / y
+                v = np.array([dx, dy])
+                v = v / np.linalg.norm(v) * np.random.uniform(0, 1)
+                state = np.array([x, y, v[0], v[1]])
+            else:
+                state = np.array([-1.0, 0.0, 0.0, 0.0])   # :44
+        else:
+            state = np.asarray(state, dtype=np.float64)
+            # the reference's guard, verbatim in behaviour (circle_base.py:46-49)
+            if not (abs(state[0] ** 2 + state[1] ** 2 - 1) < 1e-6
+                    and abs(state[0] * state[2] - state[1] * state[3]) < 1e-6):
+                raise ValueError("Can not reset to the state: ", state)
+        self.state = self._engine.reset(state=state.reshape(1, 4))[0].cpu().numpy().astype(np.float64)
+        return self.state
+
+
+class _AirHockeyFacade(_Facade):
+    def _init_common(self, task, gamma, horizon, timestep, n_intermediate_steps, env_noise, obs_noise, obs_delay,
+                     Kc, random_init, action_penalty, device, dtype):
+        if task != 'H':
+            raise NotImplementedError("only the hitting task 'H' is on the hot path (BASELINE.json configs)")
+        if env_noise or obs_noise or obs_delay:
+            raise NotImplementedError("domain randomisation (env_noise / obs_noise / obs_delay) is out of scope")
+        self.random_init = random_init
+        self._make(horizon=horizon, gamma=gamma, Kc=Kc, time_step=timestep,
+                   n_intermediate_steps=n_intermediate_steps, action_penalty=action_penalty, device=device,
+                   dtype=dtype)
+        st = self._engine.get_state()[0].cpu().numpy()
+        nq = self.dims['q']
+        self._init_q = st[:nq].astype(np.float64)
+
+    def reset(self, state=None):
+        nq = self.dims['q']
+        if state is not None:
+            state = np.asarray(state, dtype=np.float64)
+        else:
+            if self.random_init:                       # env_hitting.py:24-25
+                puck_pos = np.random.rand(2) * (HIT_RANGE[:, 1] - HIT_RANGE[:, 0]) + HIT_RANGE[:, 0]
+            else:                                      # :27
+                puck_pos = np.mean(HIT_RANGE, axis=1)
+            state = np.concatenate([self._init_q, np.zeros(nq), puck_pos, np.zeros(4)])
+        self.state = self._engine.reset(state=state.reshape(1, -1))[0].cpu().numpy().astype(np.float64)
+        return self.state
+
+
+class AirHockeyPlanarAtacom(_AirHockeyFacade):
+    _env_name = 'planar'
+
+    def __init__(self, task='H', gamma=0.99, horizon=120, timestep=1 / 240., n_intermediate_steps=4,
+                 debug_gui=False, env_noise=False, obs_noise=False, obs_delay=False, Kc=240., random_init=False,
+                 action_penalty=1e-3, device='cuda:0', dtype=torch.float32):
+        self._init_common(task, gamma, horizon, timestep, n_intermediate_steps, env_noise, obs_noise, obs_delay,
+                          Kc, random_init, action_penalty, device, dtype)
+
+
+class AirHockeyIiwaAtacom(_AirHockeyFacade):
+    _env_name = 'iiwa'
+
+    def __init__(self, task='H', gamma=0.99, horizon=120, timestep=1 / 240., n_intermediate_steps=4,
+                 debug_gui=False, env_noise=False, obs_noise=False, obs_delay=False, Kc=240., random_init=False,
+                 action_penalty=1e-3, device='cuda:0', dtype=torch.float32):
+        self._init_common(task, gamma, horizon, timestep, n_intermediate_steps, env_noise, obs_noise, obs_delay,
+                          Kc, random_init, action_penalty, device, dtype)
