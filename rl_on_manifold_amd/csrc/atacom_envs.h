@@ -256,11 +256,13 @@ __device__ __forceinline__ void constraint_terms(Iiwa, const Params<T>& P, const
         Je[0][i] = col[0]; Je[1][i] = col[1]; Je[2][i] = col[2];
         jac_col(k, i, k.p7, col);
         J7[0][i] = col[0]; J7[1][i] = col[1]; J7[2][i] = col[2];
-        if (i < 3) {
+        if (i < 2) {
             jac_col(k, i, k.p4, col);
             J4[0][i] = col[0]; J4[1][i] = col[1]; J4[2][i] = col[2];
         } else {
-            J4[0][i] = J4[1][i] = J4[2][i] = T(0);     // joint 4's axis passes through link_4's origin
+            // link_4's origin lies ON the axes of joints 3 and 4 (offset 0.2155 along z of link_3,
+            // iiwa_1.urdf:184): those columns are structurally zero; joints 5, 6 are past the frame
+            J4[0][i] = J4[1][i] = J4[2][i] = T(0);
         }
     }
     T ae[3], a4[3], a7[3];

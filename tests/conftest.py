@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope='session')
+def golden():
+    import numpy as np
+
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name + '.npz'))
+    return load
+
+
+@pytest.fixture(scope='session')
+def lib_built():
+    """Build the HIP library once per session (hipcc cross-compiles gfx950 without a GPU)."""
+    from rl_on_manifold_amd import build
+    return build.build(verbose=False)

@@ -1,0 +1,79 @@
+"""CPU-only checks of the drop-in boundary: the library builds for gfx950, loads, exports every symbol
+include/atacom_hip.h declares, and its POD config agrees with the ctypes mirror and with the oracle's
+constants.  No compute call is made (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+from oracle import atacom_scalar as osc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, 'include', 'atacom_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(atacom_[a-z_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol(lib_built):
+    from rl_on_manifold_amd import _lib
+    names = _declared_functions()
+    assert len(names) >= 14
+    lib = ctypes.CDLL(lib_built)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(_lib.EXPORTS) == names
+    assert _lib.load().atacom_version().startswith(b'atacom_hip')
+
+
+def test_config_layout_and_reference_constants(lib_built):
+    from rl_on_manifold_amd import _lib
+    for env_id, spec in ((0, osc.circle_spec()), (1, osc.planar_spec()), (2, osc.iiwa_spec())):
+        cfg = _lib.default_config(env_id)
+        assert cfg.struct_size == ctypes.sizeof(_lib.AtacomConfig)
+        d = _lib.get_dims(env_id)
+        assert (d.dim_q, d.n_f, d.n_g, d.n_null, d.obs_dim) == (spec.dim_q, spec.n_f, spec.n_g, spec.n_null, spec.obs_dim)
+        assert d.state_dim == 2 * spec.dim_q + spec.n_g + 10
+        assert cfg.substeps == spec.substeps and cfg.horizon == spec.horizon and cfg.hold_q == int(spec.hold_q)
+        assert abs(cfg.dt - spec.dt) < 1e-18 and cfg.rref_tol == spec.rref_tol
+        assert np.allclose(list(cfg.K)[:spec.n_c], spec.K) and np.allclose(list(cfg.Kc)[:spec.n_c], spec.Kc)
+        nq = spec.dim_q
+        assert np.allclose(list(cfg.vel_max)[:nq], spec.vel_max) and np.allclose(list(cfg.acc_max)[:nq], spec.acc_max)
+        assert np.allclose(list(cfg.Kq)[:nq], spec.Kq)
+        assert np.allclose(list(cfg.base_xy), spec.base_xy)
+
+
+def test_error_reporting_without_gpu(lib_built):
+    from rl_on_manifold_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.AtacomConfig()
+    assert lib.atacom_default_config(99, ctypes.byref(cfg)) == -1
+    assert b'unknown env_id' in lib.atacom_last_error()
+    d = _lib.AtacomDims()
+    assert lib.atacom_get_dims(7, ctypes.byref(d)) == -1
+    cfg = _lib.default_config(2)
+    cfg.struct_size = 8
+    h = ctypes.c_void_p()
+    assert lib.atacom_create(ctypes.byref(cfg), 0, ctypes.byref(h)) == -1
+    assert b'struct_size' in lib.atacom_last_error()
+    assert lib.atacom_step(None, None, None, None, None, None, None) == -1
+    assert lib.atacom_destroy(None) == 0
+
+
+def test_engine_refuses_to_run_without_gpu(lib_built):
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from rl_on_manifold_amd import BatchedAtacomEnv, AtacomError
+    with pytest.raises(AtacomError):
+        BatchedAtacomEnv('circle', 4)
+
+
+def test_flop_model_is_consistent():
+    import bench
+    assert 45000 < bench.algorithmic_flops('iiwa') < 60000       # ~50 kFLOP / env-step
+    assert bench.algorithmic_flops('circle') < bench.algorithmic_flops('planar') < bench.algorithmic_flops('iiwa')

@@ -1,0 +1,106 @@
+"""Oracle pinned to the reference on whole env steps: CircleEnvAtacom trajectories (G4) and the reference's
+generic AtacomEnvWrapper at the planar / iiwa shapes (G5, 4 sub-steps with the zero-order hold of q, dq).
+
+The closed loop is sensitive (saturated truncation + rref chart switches): a 1e-16 perturbation grows to
+O(1) within ~150 steps on some trajectories even in float64, so whole-trajectory equality is only asserted
+over a short free-running window; every step is asserted with "teacher forcing" (the golden state of step
+t-1 is injected, step t compared)."""
+import numpy as np
+import pytest
+
+from oracle import atacom_scalar as osc
+from oracle import atacom_batched as ob
+
+
+def test_circle_scalar_teacher_forced_and_logs(golden):
+    g = golden('circle_traj')
+    spec = osc.circle_spec()
+    for i in range(len(g['init'])):
+        env = osc.ScalarAtacomEnv(spec)
+        for t in range(0, 500, 3):
+            prev = g['init'][i] if t == 0 else g['obs'][i, t - 1]
+            s_prev = g['s0'][i] if t == 0 else g['s'][i, t - 1]
+            env.q, env.dq, env.s = prev[:2].copy(), prev[2:].copy(), s_prev.copy()
+            obs, r, ab, _, dbg = env.step(g['actions'][i, t], return_debug=True)
+            assert np.allclose(obs, g['obs'][i, t], atol=1e-12)
+            assert np.allclose(env.s, g['s'][i, t], atol=1e-12)
+            assert abs(r - g['reward'][i, t]) < 1e-13 and ab is False
+            mu_ref = g['act_a'][i, t] + g['act_b'][i, t] + g['act_err'][i, t]
+            assert np.allclose(dbg[0], mu_ref, atol=1e-9)
+
+
+def test_circle_free_running_and_constraint_logs(golden):
+    g = golden('circle_traj')
+    spec = osc.circle_spec()
+    n = len(g['init'])
+    env = ob.BatchedAtacomEnv(spec, n)
+    env.set_state(g['init'][:, :2], g['init'][:, 2:], g['s0'])
+    err = np.zeros((500, n))
+    for t in range(500):
+        obs, r, ab, _ = env.step(g['actions'][:, t])
+        err[t] = np.abs(obs - g['obs'][:, t]).max(-1)
+    assert err[:60].max() < 1e-9                      # every trajectory, first 60 steps
+    tame = err.max(0) < 1e-6
+    assert tame.sum() >= n - 5                        # most trajectories stay together for all 500 steps
+    # constraint statistics of the reference (circle_base.py:109-115) for trajectory 0 (fixed init)
+    e0 = osc.ScalarAtacomEnv(spec)
+    for t in range(500):
+        e0.step(g['actions'][0, t])
+    assert np.allclose(e0.get_constraints_logs(), g['logs'][0], atol=1e-9)
+
+
+def test_circle_reset_guard(golden):
+    g = golden('circle_reset_guard')
+    for st, ok in zip(g['states'], g['accepted']):
+        env = osc.ScalarAtacomEnv(osc.circle_spec())
+        if ok:
+            env.reset(st[:2], st[2:])
+        else:
+            with pytest.raises(ValueError):
+                env.reset(st[:2], st[2:])
+
+
+@pytest.mark.parametrize('name', ['planar', 'iiwa'])
+def test_generic_wrapper_teacher_forced(golden, name):
+    g = golden('generic_traj')
+    spec = osc.planar_spec() if name == 'planar' else osc.iiwa_spec()
+    init, acts, obs, s, s0, mu = (g[name + '_' + k] for k in ('init', 'actions', 'obs', 's', 's0', 'mu'))
+    n, T = acts.shape[:2]
+    nq = spec.dim_q
+    # batched oracle (the HIP kernels' algorithm): every step of every trajectory
+    env = ob.BatchedAtacomEnv(spec, n, init_q=g[name + '_init_q'])
+    for t in range(T):
+        if t == 0:
+            env.set_state(init[:, :nq], init[:, nq:], s0)
+        else:
+            env.set_state(obs[:, t - 1, 6:6 + nq], obs[:, t - 1, 6 + nq:], s[:, t - 1])
+        o, r, ab, _ = env.step(acts[:, t])
+        assert np.allclose(o, obs[:, t], atol=1e-9), (t, np.abs(o - obs[:, t]).max())
+        assert np.allclose(env.s, s[:, t], atol=1e-9)
+    # scalar oracle (reference's algorithmic shape, scipy SVD): a sample of steps, incl. per-sub-step mu
+    senv = osc.ScalarAtacomEnv(spec, init_q=g[name + '_init_q'])
+    for i in range(0, n, 3):
+        for t in range(0, T, 11):
+            q, dq, ss = (init[i, :nq], init[i, nq:], s0[i]) if t == 0 else \
+                (obs[i, t - 1, 6:6 + nq], obs[i, t - 1, 6 + nq:], s[i, t - 1])
+            senv.q, senv.dq, senv.s = q.copy(), dq.copy(), ss.copy()
+            o, r, ab, _, dbg = senv.step(acts[i, t], return_debug=True)
+            assert np.allclose(o, obs[i, t], atol=1e-9)
+            assert np.allclose(np.array(dbg), mu[i, t], atol=1e-7 * max(1.0, np.abs(mu[i, t]).max()))
+
+
+@pytest.mark.parametrize('name', ['planar', 'iiwa'])
+def test_generic_wrapper_constraint_logs(golden, name):
+    """Free-running statistics: same order of magnitude as the reference's logs (atacom.py:207-216)."""
+    g = golden('generic_traj')
+    spec = osc.planar_spec() if name == 'planar' else osc.iiwa_spec()
+    init, acts, s0, logs = (g[name + '_' + k] for k in ('init', 'actions', 's0', 'logs'))
+    n, T = acts.shape[:2]
+    nq = spec.dim_q
+    env = ob.BatchedAtacomEnv(spec, n, init_q=g[name + '_init_q'])
+    env.set_state(init[:, :nq], init[:, nq:], s0)
+    for t in range(T):
+        env.step(acts[:, t])
+    c_avg, c_max, c_dq = env.get_constraints_logs()
+    assert c_max < max(1.5 * logs[:, 1].max(), logs[:, 1].max() + 0.02)
+    assert c_dq <= 1e-6
