@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libatacom_hip.so')
+# ATACOM_LIB lets kernel-tuning experiments point at an alternative build of the same library
+LIB_PATH = os.environ.get('ATACOM_LIB') or os.path.join(HERE, 'libatacom_hip.so')
 
 ENV_CIRCLE, ENV_PLANAR, ENV_IIWA = 0, 1, 2
 F32, F64 = 0, 1
@@ -22,7 +23,7 @@ class AtacomConfig(C.Structure):
     """Mirror of `atacom_config` (include/atacom_hip.h)."""
     _fields_ = [('struct_size', C.c_int32), ('env_id', C.c_int32), ('batch', C.c_int32), ('dtype', C.c_int32),
                 ('substeps', C.c_int32), ('horizon', C.c_int32), ('hold_q', C.c_int32), ('bias_mode', C.c_int32),
-                ('auto_reset', C.c_int32), ('reserved0', C.c_int32),
+                ('auto_reset', C.c_int32), ('lanes_per_env', C.c_int32),
                 ('dt', C.c_double), ('rref_tol', C.c_double), ('action_penalty', C.c_double), ('gamma', C.c_double),
                 ('K', C.c_double * MAX_C), ('Kc', C.c_double * MAX_C), ('vel_max', C.c_double * MAX_Q),
                 ('acc_max', C.c_double * MAX_Q), ('Kq', C.c_double * MAX_Q), ('pos_limit', C.c_double * MAX_Q),
@@ -61,7 +62,7 @@ def load():
     lib.atacom_get_stats.argtypes = [vp, C.POINTER(C.c_double * 3), i32, vp]
     lib.atacom_get_state.argtypes = [vp, vp, vp]
     lib.atacom_set_state.argtypes = [vp, vp, vp]
-    lib.atacom_nullspace.argtypes = [i32, i32, i32, vp, vp, C.c_double, vp, vp, vp, vp]
+    lib.atacom_nullspace.argtypes = [i32, i32, i32, i32, vp, vp, C.c_double, vp, vp, vp, vp]
     lib.atacom_constraint_terms.argtypes = [C.POINTER(AtacomConfig), i32, vp, vp, vp, vp, vp, vp]
     lib.atacom_last_error.restype = C.c_char_p
     lib.atacom_version.restype = C.c_char_p

@@ -12,10 +12,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-LIB = os.path.join(HERE, 'libatacom_hip.so')
+LIB = os.environ.get('ATACOM_LIB_OUT') or os.path.join(HERE, 'libatacom_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
-FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + \
+    os.environ.get('ATACOM_HIPCC_FLAGS', '').split()
 UNITS = ['atacom_circle.hip', 'atacom_planar.hip', 'atacom_iiwa.hip', 'atacom_capi.cpp']
 
 
@@ -34,7 +35,7 @@ def needs_build():
 
 def _compile(unit):
     src = os.path.join(CSRC, unit)
-    obj = os.path.join(CSRC, os.path.splitext(unit)[0] + '.o')
+    obj = os.path.join(CSRC, os.path.splitext(unit)[0] + os.environ.get('ATACOM_OBJ_TAG', '') + '.o')
     cmd = [HIPCC] + FLAGS + (['-x', 'hip'] if unit.endswith('.cpp') else []) + ['-c', src, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -38,6 +38,14 @@ const atacom::EnvOps* get_ops(int env_id, int dtype) {
 
 constexpr int kStatBlocks = 256;
 
+// kernel mapping policy for lanes_per_env = 0 (measured on MI355X, profiles/): the quad-cooperative
+// kernels win whenever the 12x17 problem is solved (iiwa); the small environments are launch-bound.
+int pick_lanes(const atacom_config& c) {
+    if (c.lanes_per_env == 1 || c.lanes_per_env == 4) return c.lanes_per_env;
+    if (c.dtype == ATACOM_F64) return 1;
+    return c.env_id == ATACOM_ENV_IIWA ? 4 : 1;
+}
+
 // default initial state rows: [q, dq, puck(6)]
 void default_init_row(int env_id, std::vector<double>& row) {
     const double puck[6] = {-0.4, 0.0, 0.0, 0.0, 0.0, 0.0};   // centre of hit_range, env_hitting.py:11,27
@@ -88,6 +96,7 @@ int atacom_default_config(int32_t env_id, atacom_config* c) {
     c->hold_q = 1;
     c->bias_mode = 0;
     c->auto_reset = 0;
+    c->lanes_per_env = 0;
     c->rref_tol = 0.05;          // atacom.py:128
     c->gamma = 0.99;
     c->action_penalty = 1e-3;    // env_hitting.py:10
@@ -137,6 +146,8 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
     if (!ops) return fail(ATACOM_E_INVALID, "atacom_create: unknown env_id / dtype");
     if (cfg->batch <= 0 || cfg->substeps <= 0 || cfg->horizon <= 0 || !(cfg->dt > 0))
         return fail(ATACOM_E_INVALID, "atacom_create: batch, substeps, horizon and dt must be positive");
+    if (cfg->lanes_per_env != 0 && cfg->lanes_per_env != 1 && cfg->lanes_per_env != 4)
+        return fail(ATACOM_E_INVALID, "atacom_create: lanes_per_env must be 0 (auto), 1 or 4");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(ATACOM_E_INVALID, "atacom_create: no such device");
@@ -203,7 +214,7 @@ int atacom_step(atacom_handle* h, const void* d_action, void* d_obs, void* d_rew
     if (!d_action || !d_obs || !d_reward || !d_absorbing)
         return fail(ATACOM_E_INVALID, "atacom_step: d_action, d_obs, d_reward and d_absorbing are required");
     HIP_TRY(hipSetDevice(h->device));
-    h->ops->step(h->cfg, h->f, h->ip, d_action, d_obs, d_reward, d_absorbing, d_last, (hipStream_t)stream);
+    h->ops->step(h->cfg, pick_lanes(h->cfg), h->f, h->ip, d_action, d_obs, d_reward, d_absorbing, d_last, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
 }
@@ -215,7 +226,7 @@ int atacom_rollout(atacom_handle* h, int32_t n_steps, const void* d_actions, voi
     if (!d_actions || !d_obs || !d_reward || !d_absorbing || !d_last)
         return fail(ATACOM_E_INVALID, "atacom_rollout: all buffers except d_next_obs are required");
     HIP_TRY(hipSetDevice(h->device));
-    h->ops->rollout(h->cfg, n_steps, h->f, h->ip, d_actions, d_obs, d_next_obs, d_reward, d_absorbing, d_last,
+    h->ops->rollout(h->cfg, pick_lanes(h->cfg), n_steps, h->f, h->ip, d_actions, d_obs, d_next_obs, d_reward, d_absorbing, d_last,
                     (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
@@ -260,12 +271,14 @@ int atacom_set_state(atacom_handle* h, const void* d_state, void* stream) {
     return ATACOM_OK;
 }
 
-int atacom_nullspace(int32_t env_id, int32_t dtype, int32_t n, const void* d_Jc, const void* d_rhs, double tol,
-                     void* d_x, void* d_null, void* d_rref, void* stream) {
+int atacom_nullspace(int32_t env_id, int32_t dtype, int32_t lanes_per_env, int32_t n, const void* d_Jc,
+                     const void* d_rhs, double tol, void* d_x, void* d_null, void* d_rref, void* stream) {
+    if (lanes_per_env != 1 && lanes_per_env != 4)
+        return fail(ATACOM_E_INVALID, "atacom_nullspace: lanes_per_env must be 1 or 4");
     const atacom::EnvOps* ops = get_ops(env_id, dtype);
     if (!ops) return fail(ATACOM_E_INVALID, "atacom_nullspace: unknown env_id / dtype");
     if (n <= 0 || !d_Jc) return fail(ATACOM_E_INVALID, "atacom_nullspace: n must be positive and d_Jc non-null");
-    ops->nullspace(n, d_Jc, d_rhs, tol, d_x, d_null, d_rref, (hipStream_t)stream);
+    ops->nullspace(lanes_per_env, n, d_Jc, d_rhs, tol, d_x, d_null, d_rref, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
 }

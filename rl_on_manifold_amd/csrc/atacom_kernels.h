@@ -11,6 +11,7 @@
 #pragma once
 #include <stdint.h>
 #include "atacom_envs.h"
+#include "atacom_quad.h"
 
 namespace atacom {
 
@@ -125,9 +126,12 @@ __device__ __forceinline__ void slack_init(const Params<T>& P, EnvState<T, E>& s
 }
 
 // ------------------------------------------------------------------ one env step (A1, A2, A13-A15)
-template <typename T, typename E>
+// LANES = 1: one environment per lane (atacom_linalg.h).  LANES = 4: one environment per DPP quad -- the
+// null-space solve is column-split over the quad (atacom_quad.h), everything else is computed redundantly
+// (and bitwise identically) by the four lanes; `lq` is the lane's index in its quad.
+template <typename T, typename E, int LANES>
 __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st, const T (&act)[E::NK],
-                                         StepOut<T>& out) {
+                                         StepOut<T>& out, const int lq) {
     constexpr int NQ = E::NQ, NF = E::NF, NG = E::NG, NC = E::NC, NN = E::NN, NK = E::NK;
     T alpha[NK];
     T anorm2 = T(0);
@@ -144,6 +148,8 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
     }
     T qc[NQ], dqc[NQ];          // what the controller sees (held over the sub-steps when hold_q)
     T A[NC][NQ], psi[NC], c0[NC];
+    constexpr int SQ = (NN + 3) / 4;
+    T Aq[NC][SQ];              // LANES == 4: this lane's columns of [K J | 0]
 #pragma unroll 1
     for (int sub = 0; sub < P.substeps; ++sub) {
         if (sub == 0 || !P.hold_q) {
@@ -163,35 +169,75 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 psi[r] = num<T>::fma(P.K[r], bst[r], jdq);      // constraints.py:42-43
                 c0[r] = num<T>::fma(P.K[r], jdq, fun[r]);       // constraints.py:33-37
             }
+            if (LANES == 4) {
+#pragma unroll
+                for (int r = 0; r < NC; ++r)
+#pragma unroll
+                    for (int sl = 0; sl < SQ; ++sl) {
+                        T cand[4];
+#pragma unroll
+                        for (int l = 0; l < 4; ++l) cand[l] = (4 * sl + l < NQ) ? A[r][4 * sl + l < NQ ? 4 * sl + l : 0] : T(0);
+                        Aq[r][sl] = lq == 0 ? cand[0] : (lq == 1 ? cand[1] : (lq == 2 ? cand[2] : cand[3]));
+                    }
+            }
         }
         // J_c = [[K_f J_f, 0], [K_g J_g, diag(s)]],  rhs = psi + K_c c     (atacom.py:151-165,183-196)
-        T a[NC][NN], y[NC], x[NN], nb[NN][NK], nmu[NN];
+        T mu[NN], y[NC];
 #pragma unroll
         for (int r = 0; r < NC; ++r) {
-#pragma unroll
-            for (int c = 0; c < NQ; ++c) a[r][c] = A[r][c];
-#pragma unroll
-            for (int g = 0; g < NG; ++g) a[r][NQ + g] = (r == NF + g) ? st.s[g] : T(0);
             const T sv = (r >= NF) ? st.s[r >= NF ? r - NF : 0] : T(0);
             const T cs = num<T>::fma(T(0.5) * sv, sv, c0[r]);       // c = fun + K J dq (+ s^2 / 2 on g rows)
             y[r] = num<T>::fma(P.Kc[r], cs, psi[r]);
         }
-        bidiag_solve_null<T, NC, NN>(a, y, x, nb);              // atacom.py:127 (pinv_null)
-        rref_apply<T, NN, NK>(nb, alpha, P.rref_tol, nmu);      // atacom.py:128,131
+        if (LANES == 1) {
+            T a[NC][NN], x[NN], nb[NN][NK], nmu[NN];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) st.s[g] = num<T>::fma(nmu[NQ + g] - x[NQ + g], P.dt, st.s[g]);   // :135
+            for (int r = 0; r < NC; ++r) {
+#pragma unroll
+                for (int c = 0; c < NQ; ++c) a[r][c] = A[r][c];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) a[r][NQ + g] = (r == NF + g) ? st.s[g] : T(0);
+            }
+            bidiag_solve_null<T, NC, NN>(a, y, x, nb);              // atacom.py:127 (pinv_null)
+            rref_apply<T, NN, NK>(nb, alpha, P.rref_tol, nmu);      // atacom.py:128,131
+#pragma unroll
+            for (int n = 0; n < NN; ++n) mu[n] = nmu[n] - x[n];     // atacom.py:130-133
+        } else {
+            constexpr int S = (NN + 3) / 4;
+            T a[NC][S], x[S], nb[S][NK], nmu[S];
+            // this lane's columns: the K J block was split once per step (Aq), the slack diagonal entry of
+            // row r sits in column NQ + r - NF, i.e. slot (NQ+r-NF)/4 of lane (NQ+r-NF)%4
+#pragma unroll
+            for (int r = 0; r < NC; ++r) {
+#pragma unroll
+                for (int sl = 0; sl < S; ++sl) a[r][sl] = Aq[r][sl];
+                if (r >= NF) {
+                    const int c = NQ + r - NF;
+                    a[r][c / 4] = (lq == c % 4) ? st.s[r >= NF ? r - NF : 0] : Aq[r][c / 4];
+                }
+            }
+            bidiag_solve_null_quad<T, NC, NN>(a, y, x, nb, lq);
+            rref_apply_quad<T, NN, NK>(nb, alpha, P.rref_tol, nmu, lq);
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {                          // gather mu back to every lane of the quad
+                const T o = nmu[n / 4] - x[n / 4];
+                mu[n] = (n % 4 == 0) ? qbcast<0>(o) : (n % 4 == 1) ? qbcast<1>(o) : (n % 4 == 2) ? qbcast<2>(o) : qbcast<3>(o);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) st.s[g] = num<T>::fma(mu[NQ + g], P.dt, st.s[g]);   // :135
         T ddq[NQ];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {                          // acc_truncation, atacom.py:117-121
             const T up = num<T>::max(num<T>::min(P.acc_max[i], -P.Kq[i] * (dqc[i] - P.vel_max[i])), -P.acc_max[i]);
             const T lo = num<T>::min(num<T>::max(-P.acc_max[i], -P.Kq[i] * (dqc[i] + P.vel_max[i])), P.acc_max[i]);
-            ddq[i] = num<T>::min(num<T>::max(nmu[i] - x[i], lo), up);
+            ddq[i] = num<T>::min(num<T>::max(mu[i], lo), up);
         }
         if (E::ID == 0) {
             // circle_atacom.py:26-27 + circle_base.py:59-63
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
-                const T acc = num<T>::min(num<T>::max(ddq[i] / P.acc_max[i], T(-1)), T(1)) * T(10);
+                const T acc = num<T>::min(num<T>::max(num<T>::div(ddq[i], P.acc_max[i]), T(-1)), T(1)) * T(10);
                 st.q[i] += num<T>::fma(st.dq[i], P.dt, acc * (P.dt * P.dt) / T(2));
                 st.dq[i] = num<T>::fma(acc, P.dt, st.dq[i]);
             }
@@ -231,7 +277,8 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
         const T dist = num<T>::sqrt(num<T>::fma(dx, dx, dy * dy));
         const T gx = P.goal_x - st.puck[0], gy = P.goal_y - st.puck[1];
         const T gn = num<T>::sqrt(num<T>::fma(gx, gx, gy * gy));
-        T cosang = ((gx / gn) * (dx / dist)) + ((gy / gn) * (dy / dist));
+        const T ign = num<T>::rcp(gn), idist = num<T>::rcp(dist);
+        T cosang = ((gx * ign) * (dx * idist)) + ((gy * ign) * (dy * idist));
         cosang = num<T>::min(num<T>::max(cosang, T(0)), T(1));
         const T r_app = num<T>::exp(T(-8) * (dist - T(0.08))) * cosang;
         const bool upd = !ab && (st.has_hit == 0);
@@ -255,14 +302,16 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
 }
 
 // ------------------------------------------------------------------ kernels
-template <typename T, typename E>
+template <typename T, typename E, int LANES>
 __global__ void __launch_bounds__(WAVE) k_step(const Params<T> P, T* __restrict__ f, int* __restrict__ ip,
                                                const T* __restrict__ action, T* __restrict__ obs,
                                                T* __restrict__ reward, uint8_t* __restrict__ absorbing,
                                                uint8_t* __restrict__ last) {
     using L = Planes<E>;
     const int B = P.batch;
-    const int b = blockIdx.x * WAVE + threadIdx.x;
+    const int gt = blockIdx.x * WAVE + threadIdx.x;
+    const int b = gt / LANES;                  // whole quads leave together (WAVE % LANES == 0)
+    const int lq = gt % LANES;
     if (b >= B) return;
     EnvState<T, E> st;
     load_state<T, E>(f, ip, B, b, st);
@@ -270,7 +319,8 @@ __global__ void __launch_bounds__(WAVE) k_step(const Params<T> P, T* __restrict_
 #pragma unroll
     for (int k = 0; k < E::NK; ++k) act[k] = action[(size_t)b * E::NK + k];
     StepOut<T> out;
-    env_step<T, E>(P, st, act, out);
+    env_step<T, E, LANES>(P, st, act, out, lq);
+    if (lq != 0) return;                       // the four lanes hold identical results; lane 0 writes
     write_obs<T, E>(P, st, obs + (size_t)b * E::OBS);
     reward[b] = out.reward;
     absorbing[b] = out.absorbing ? 1 : 0;
@@ -283,7 +333,7 @@ __global__ void __launch_bounds__(WAVE) k_step(const Params<T> P, T* __restrict_
     store_state<T, E>(f, ip, B, b, st);
 }
 
-template <typename T, typename E>
+template <typename T, typename E, int LANES>
 __global__ void __launch_bounds__(WAVE) k_rollout(const Params<T> P, int n_steps, T* __restrict__ f,
                                                   int* __restrict__ ip, const T* __restrict__ actions,
                                                   T* __restrict__ obs, T* __restrict__ next_obs,
@@ -291,7 +341,9 @@ __global__ void __launch_bounds__(WAVE) k_rollout(const Params<T> P, int n_steps
                                                   uint8_t* __restrict__ last) {
     using L = Planes<E>;
     const int B = P.batch;
-    const int b = blockIdx.x * WAVE + threadIdx.x;
+    const int gt = blockIdx.x * WAVE + threadIdx.x;
+    const int b = gt / LANES;
+    const int lq = gt % LANES;
     if (b >= B) return;
     EnvState<T, E> st;
     load_state<T, E>(f, ip, B, b, st);
@@ -299,21 +351,24 @@ __global__ void __launch_bounds__(WAVE) k_rollout(const Params<T> P, int n_steps
 #pragma unroll 1
     for (int t = 0; t < n_steps; ++t) {
         const size_t row = (size_t)t * B + b;
-        write_obs<T, E>(P, st, obs + row * E::OBS);
+        if (lq == 0) write_obs<T, E>(P, st, obs + row * E::OBS);
         T act[E::NK];
 #pragma unroll
         for (int k = 0; k < E::NK; ++k) act[k] = actions[row * E::NK + k];
         StepOut<T> out;
-        env_step<T, E>(P, st, act, out);
-        if (next_obs) write_obs<T, E>(P, st, next_obs + row * E::OBS);
-        reward[row] = out.reward;
-        absorbing[row] = out.absorbing ? 1 : 0;
-        last[row] = out.last ? 1 : 0;
+        env_step<T, E, LANES>(P, st, act, out, lq);
+        if (lq == 0) {
+            if (next_obs) write_obs<T, E>(P, st, next_obs + row * E::OBS);
+            reward[row] = out.reward;
+            absorbing[row] = out.absorbing ? 1 : 0;
+            last[row] = out.last ? 1 : 0;
+        }
         ssum += out.log_avg;
         scmax = num<T>::max(scmax, out.log_max);
         sdq = num<T>::max(sdq, out.log_dq);
         if (P.auto_reset && out.last) load_init<T, E>(f, B, b, st);
     }
+    if (lq != 0) return;
     f[L::SSUM * (size_t)B + b] += ssum;
     f[L::SCMAX * (size_t)B + b] = scmax;
     f[L::SDQMAX * (size_t)B + b] = sdq;
@@ -495,6 +550,57 @@ __global__ void __launch_bounds__(WAVE) k_nullspace(int n, const T* __restrict__
             rref_apply<T, NN, NK>(nb2, alpha, tol, col);
 #pragma unroll
             for (int c = 0; c < NN; ++c) rrefo[((size_t)b * NN + c) * NK + k] = col[c];
+        }
+    }
+}
+
+// the same primitive through the quad-cooperative solver (4 lanes per matrix)
+template <typename T, typename E>
+__global__ void __launch_bounds__(WAVE) k_nullspace_quad(int n, const T* __restrict__ Jc, const T* __restrict__ rhs,
+                                                         T tol, T* __restrict__ xo, T* __restrict__ nullo,
+                                                         T* __restrict__ rrefo) {
+    constexpr int NC = E::NC, NN = E::NN, NK = E::NK, S = (NN + 3) / 4;
+    const int gt = blockIdx.x * WAVE + threadIdx.x;
+    const int b = gt >> 2, lq = gt & 3;
+    if (b >= n) return;
+    T a[NC][S], y[NC], x[S], nb[S][NK];
+#pragma unroll
+    for (int r = 0; r < NC; ++r) {
+        y[r] = rhs ? rhs[(size_t)b * NC + r] : T(0);
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl) {
+            const int c = 4 * sl + lq;
+            a[r][sl] = (c < NN) ? Jc[((size_t)b * NC + r) * NN + (c < NN ? c : 0)] : T(0);
+        }
+    }
+    bidiag_solve_null_quad<T, NC, NN>(a, y, x, nb, lq);
+#pragma unroll
+    for (int sl = 0; sl < S; ++sl) {
+        const int c = 4 * sl + lq;
+        if (c < NN) {
+            if (xo) xo[(size_t)b * NN + c] = x[sl];
+            if (nullo) {
+#pragma unroll
+                for (int k = 0; k < NK; ++k) nullo[((size_t)b * NN + c) * NK + k] = nb[sl][k];
+            }
+        }
+    }
+    if (rrefo) {
+#pragma unroll 1
+        for (int k = 0; k < NK; ++k) {
+            T nb2[S][NK], alpha[NK], col[S];
+#pragma unroll
+            for (int sl = 0; sl < S; ++sl)
+#pragma unroll
+                for (int j = 0; j < NK; ++j) nb2[sl][j] = nb[sl][j];
+#pragma unroll
+            for (int j = 0; j < NK; ++j) alpha[j] = (j == k) ? T(1) : T(0);
+            rref_apply_quad<T, NN, NK>(nb2, alpha, tol, col, lq);
+#pragma unroll
+            for (int sl = 0; sl < S; ++sl) {
+                const int c = 4 * sl + lq;
+                if (c < NN) rrefo[((size_t)b * NN + c) * NK + k] = col[sl];
+            }
         }
     }
 }

@@ -22,18 +22,35 @@
 namespace atacom {
 
 template <typename T> struct num;
+// float: v_rcp_f32 / v_sqrt_f32 (1 ulp) instead of the ~10-instruction IEEE division / sqrt expansions -- the
+// step is a latency-bound dependent chain and 1-2 ulp is far inside the stated float32 parity tolerance.
+// double (parity build): correctly rounded operations.
 template <> struct num<float> {
+#ifdef ATACOM_IEEE_DIV
     static __device__ __forceinline__ float sqrt(float x) { return __builtin_sqrtf(x); }
+    static __device__ __forceinline__ float rcp(float x) { return 1.0f / x; }
+    static __device__ __forceinline__ float div(float a, float b) { return a / b; }
+#else
+    static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+    static __device__ __forceinline__ float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#endif
     static __device__ __forceinline__ float abs(float x) { return __builtin_fabsf(x); }
     static __device__ __forceinline__ float copysign(float m, float s) { return __builtin_copysignf(m, s); }
     static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     static __device__ __forceinline__ float exp(float x) { return expf(x); }
+#ifdef ATACOM_FAST_TRIG
+    static __device__ __forceinline__ void sincos(float x, float* s, float* c) { __sincosf(x, s, c); }
+#else
     static __device__ __forceinline__ void sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+#endif
     static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
     static __device__ __forceinline__ float min(float a, float b) { return fminf(a, b); }
 };
 template <> struct num<double> {
     static __device__ __forceinline__ double sqrt(double x) { return __builtin_sqrt(x); }
+    static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+    static __device__ __forceinline__ double div(double a, double b) { return a / b; }
     static __device__ __forceinline__ double abs(double x) { return __builtin_fabs(x); }
     static __device__ __forceinline__ double copysign(double m, double s) { return __builtin_copysign(m, s); }
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -52,9 +69,9 @@ __device__ __forceinline__ T larfg_scale(T alpha, T ss, T& beta, T& tau) {
     const T b = -num<T>::copysign(nrm, alpha);
     beta = nz ? b : alpha;
     const T safe_b = nz ? b : T(1);
-    tau = nz ? (b - alpha) / safe_b : T(0);
+    tau = nz ? num<T>::div(b - alpha, safe_b) : T(0);
     const T den = nz ? (alpha - b) : T(1);
-    return nz ? T(1) / den : T(0);
+    return nz ? num<T>::rcp(den) : T(0);
 }
 
 // a: M x N (row i, col j), full row rank; y: right-hand side (length M).
@@ -119,9 +136,9 @@ __device__ __forceinline__ void bidiag_solve_null(T (&a)[M][N], T (&y)[M], T (&x
         }
     }
     // ---- z = B^{-1} (Q^T y), B lower bidiagonal (d on the diagonal, e below it)
-    x[0] = y[0] / d[0];
+    x[0] = num<T>::div(y[0], d[0]);
 #pragma unroll
-    for (int i = 1; i < M; ++i) x[i] = num<T>::fma(-e[i - 1], x[i - 1], y[i]) / d[i];
+    for (int i = 1; i < M; ++i) x[i] = num<T>::div(num<T>::fma(-e[i - 1], x[i - 1], y[i]), d[i]);
 #pragma unroll
     for (int c = M; c < N; ++c) x[c] = T(0);
 #pragma unroll
@@ -184,7 +201,7 @@ __device__ __forceinline__ void rref_apply(T (&nb)[N][K], const T (&alpha)[K], T
             T pj = T(0);
 #pragma unroll
             for (int r = 0; r < K; ++r) pj = (r == kk) ? nb[j][r] : pj;
-            const T inv = piv ? T(1) / pj : T(0);
+            const T inv = piv ? num<T>::rcp(pj) : T(0);
             T f[K];
 #pragma unroll
             for (int r = 0; r < K; ++r) {

@@ -10,10 +10,11 @@ namespace atacom {
 struct EnvOps {
     int n_planes, n_iplanes, state_dim, init_dim, obs_dim, nq, nf, ng, nk;
     size_t elem;
-    void (*step)(const atacom_config&, void* f, int* ip, const void* act, void* obs, void* rew, uint8_t* ab,
-                 uint8_t* last, hipStream_t s);
-    void (*rollout)(const atacom_config&, int n_steps, void* f, int* ip, const void* acts, void* obs, void* nobs,
-                    void* rew, uint8_t* ab, uint8_t* last, hipStream_t s);
+    // lanes = 1 or 4 (lanes per environment)
+    void (*step)(const atacom_config&, int lanes, void* f, int* ip, const void* act, void* obs, void* rew,
+                 uint8_t* ab, uint8_t* last, hipStream_t s);
+    void (*rollout)(const atacom_config&, int lanes, int n_steps, void* f, int* ip, const void* acts, void* obs,
+                    void* nobs, void* rew, uint8_t* ab, uint8_t* last, hipStream_t s);
     void (*reset)(const atacom_config&, void* f, int* ip, const uint8_t* mask, const void* init, void* obs,
                   hipStream_t s);
     void (*fill_init)(const atacom_config&, void* f, int* ip, const void* row, hipStream_t s);
@@ -21,7 +22,7 @@ struct EnvOps {
     void (*stats)(const atacom_config&, const void* f, const int* ip, double* partial, int nblocks, hipStream_t s);
     void (*get_state)(const atacom_config&, const void* f, const int* ip, void* out, hipStream_t s);
     void (*set_state)(const atacom_config&, void* f, int* ip, const void* in, hipStream_t s);
-    void (*nullspace)(int n, const void* Jc, const void* rhs, double tol, void* x, void* nullb, void* rref,
+    void (*nullspace)(int lanes, int n, const void* Jc, const void* rhs, double tol, void* x, void* nullb, void* rref,
                       hipStream_t s);
     void (*terms)(const atacom_config&, int n, const void* q, const void* dq, void* fun, void* J, void* b,
                   hipStream_t s);

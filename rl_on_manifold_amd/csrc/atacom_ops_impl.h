@@ -36,15 +36,24 @@ static inline int nblk(int n, int per) { return (n + per - 1) / per; }
 template <typename T, typename E>
 struct Ops {
     using L = Planes<E>;
-    static void step(const atacom_config& c, void* f, int* ip, const void* act, void* obs, void* rew, uint8_t* ab,
-                     uint8_t* last, hipStream_t s) {
-        hipLaunchKernelGGL((k_step<T, E>), dim3(nblk(c.batch, WAVE)), dim3(WAVE), 0, s, make_params<T>(c), (T*)f, ip,
-                           (const T*)act, (T*)obs, (T*)rew, ab, last);
+    static void step(const atacom_config& c, int lanes, void* f, int* ip, const void* act, void* obs, void* rew,
+                     uint8_t* ab, uint8_t* last, hipStream_t s) {
+        if (lanes == 4)
+            hipLaunchKernelGGL((k_step<T, E, 4>), dim3(nblk(c.batch * 4, WAVE)), dim3(WAVE), 0, s, make_params<T>(c),
+                               (T*)f, ip, (const T*)act, (T*)obs, (T*)rew, ab, last);
+        else
+            hipLaunchKernelGGL((k_step<T, E, 1>), dim3(nblk(c.batch, WAVE)), dim3(WAVE), 0, s, make_params<T>(c),
+                               (T*)f, ip, (const T*)act, (T*)obs, (T*)rew, ab, last);
     }
-    static void rollout(const atacom_config& c, int n_steps, void* f, int* ip, const void* acts, void* obs,
+    static void rollout(const atacom_config& c, int lanes, int n_steps, void* f, int* ip, const void* acts, void* obs,
                         void* nobs, void* rew, uint8_t* ab, uint8_t* last, hipStream_t s) {
-        hipLaunchKernelGGL((k_rollout<T, E>), dim3(nblk(c.batch, WAVE)), dim3(WAVE), 0, s, make_params<T>(c),
-                           n_steps, (T*)f, ip, (const T*)acts, (T*)obs, (T*)nobs, (T*)rew, ab, last);
+        if (lanes == 4)
+            hipLaunchKernelGGL((k_rollout<T, E, 4>), dim3(nblk(c.batch * 4, WAVE)), dim3(WAVE), 0, s,
+                               make_params<T>(c), n_steps, (T*)f, ip, (const T*)acts, (T*)obs, (T*)nobs, (T*)rew, ab,
+                               last);
+        else
+            hipLaunchKernelGGL((k_rollout<T, E, 1>), dim3(nblk(c.batch, WAVE)), dim3(WAVE), 0, s, make_params<T>(c),
+                               n_steps, (T*)f, ip, (const T*)acts, (T*)obs, (T*)nobs, (T*)rew, ab, last);
     }
     static void reset(const atacom_config& c, void* f, int* ip, const uint8_t* mask, const void* init, void* obs,
                       hipStream_t s) {
@@ -70,10 +79,14 @@ struct Ops {
         hipLaunchKernelGGL((k_set_state<T, E>), dim3(nblk(c.batch, 256)), dim3(256), 0, s, c.batch, (T*)f, ip,
                            (const T*)in);
     }
-    static void nullspace(int n, const void* Jc, const void* rhs, double tol, void* x, void* nullb, void* rref,
-                          hipStream_t s) {
-        hipLaunchKernelGGL((k_nullspace<T, E>), dim3(nblk(n, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,
-                           (const T*)rhs, (T)tol, (T*)x, (T*)nullb, (T*)rref);
+    static void nullspace(int lanes, int n, const void* Jc, const void* rhs, double tol, void* x, void* nullb,
+                          void* rref, hipStream_t s) {
+        if (lanes == 4)
+            hipLaunchKernelGGL((k_nullspace_quad<T, E>), dim3(nblk(n * 4, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,
+                               (const T*)rhs, (T)tol, (T*)x, (T*)nullb, (T*)rref);
+        else
+            hipLaunchKernelGGL((k_nullspace<T, E>), dim3(nblk(n, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,
+                               (const T*)rhs, (T)tol, (T*)x, (T*)nullb, (T*)rref);
     }
     static void terms(const atacom_config& c, int n, const void* q, const void* dq, void* fun, void* J, void* b,
                       hipStream_t s) {

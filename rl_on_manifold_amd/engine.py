@@ -32,7 +32,7 @@ class BatchedAtacomEnv:
 
     def __init__(self, env, batch, device='cuda:0', dtype=torch.float32, horizon=None, gamma=None, Kc=None,
                  time_step=None, n_intermediate_steps=None, action_penalty=None, auto_reset=False,
-                 hold_q=None, bias_mode='reference', rref_tol=None):
+                 hold_q=None, bias_mode='reference', rref_tol=None, lanes_per_env=0):
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.AtacomError("BatchedAtacomEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -61,6 +61,7 @@ class BatchedAtacomEnv:
             cfg.hold_q = int(bool(hold_q))
         cfg.bias_mode = {'reference': 0, 'exact': 1}[bias_mode]
         cfg.auto_reset = int(bool(auto_reset))
+        cfg.lanes_per_env = int(lanes_per_env)      # 0 auto, 1 lane-per-env, 4 quad-per-env kernels
         d = _lib.get_dims(self.env_id)
         self.dims = {'q': d.dim_q, 'f': d.n_f, 'g': d.n_g, 'null': d.n_null, 'c': d.n_f + d.n_g}   # atacom.py:25-40
         self.obs_dim, self.state_dim, self.init_state_dim = d.obs_dim, d.state_dim, d.init_state_dim
@@ -176,7 +177,7 @@ class BatchedAtacomEnv:
 
 
 # ---------------------------------------------------------------------- stand-alone primitives
-def nullspace(env, Jc, rhs=None, tol=0.05):
+def nullspace(env, Jc, rhs=None, tol=0.05, lanes_per_env=1):
     """Batched pinv_null + rref on the GPU (null_space_coordinate.py:8-26,40-79).
     Jc [n, c, c+k] (torch, on a ROCm device).  Returns (x = Jc^+ rhs, null basis, rref(null, tol))."""
     lib = _lib.load()
@@ -193,7 +194,7 @@ def nullspace(env, Jc, rhs=None, tol=0.05):
     rr = torch.empty((n, c + k, k), device=Jc.device, dtype=Jc.dtype)
     stream = C.c_void_p(torch.cuda.current_stream(Jc.device).cuda_stream)
     with torch.cuda.device(Jc.device):
-        _lib.check(lib.atacom_nullspace(env_id, dt, n, _ptr(Jc), _ptr(rhs), float(tol), _ptr(x), _ptr(nb), _ptr(rr),
+        _lib.check(lib.atacom_nullspace(env_id, dt, int(lanes_per_env), n, _ptr(Jc), _ptr(rhs), float(tol), _ptr(x), _ptr(nb), _ptr(rr),
                                         stream))
     return x, nb, rr
 

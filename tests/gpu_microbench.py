@@ -1,0 +1,29 @@
+"""Kernel-tuning helper (not a pytest file): time atacom_step / rollout for one library build."""
+import os, sys, time
+import torch
+sys.path.insert(0, '.')
+from rl_on_manifold_amd import BatchedAtacomEnv
+dev = 'cuda:0'
+tag = os.environ.get('ATACOM_LIB', 'default')
+for name in sys.argv[1:] or ['iiwa']:
+    for B in (8192,):
+      for lanes in (1, 4):
+        env = BatchedAtacomEnv(name, B, device=dev, dtype=torch.float32, auto_reset=True, lanes_per_env=lanes)
+        k = env.dims['null']
+        gen = torch.Generator(device=dev); gen.manual_seed(0)
+        st = env.get_state(); nq = env.dims['q']
+        if name != 'circle':
+            init = torch.zeros((B, env.init_state_dim), device=dev)
+            init[:, :nq] = st[:, :nq] + 0.05 * torch.randn((B, nq), device=dev, generator=gen)
+            init[:, 2 * nq:] = st[:, 2 * nq + env.dims['g']: 2 * nq + env.dims['g'] + 6]
+            env.reset(state=init)
+        a = torch.rand((16, B, k), device=dev, generator=gen) * 2 - 1
+        for i in range(10): env.step_into(a[i % 16], env._obs, env._reward, env._absorbing, env._last)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 100
+        e0.record()
+        for i in range(n): env.step_into(a[i % 16], env._obs, env._reward, env._absorbing, env._last)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / n * 1e3
+        print('%s %s lanes=%d B=%d step %.1f us -> %.3g env-steps/s  logs %s' % (os.path.basename(tag), name, lanes, B, us, B / us * 1e6, env.get_constraints_logs()), flush=True)
