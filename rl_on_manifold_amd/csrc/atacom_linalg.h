@@ -170,84 +170,100 @@ __device__ __forceinline__ void bidiag_solve_null(T (&a)[M][N], T (&y)[M], T (&x
     }
 }
 
-// Gauss-Jordan "chart" of the null basis with the reference's pivot tolerance
-// (null_space_coordinate.py:40-79 called with row_vectors=False, tol): operates on V = nb^T (K x N).
-// Branch-free per lane; rows are not physically swapped -- instead each row remembers the order in
-// which it became a pivot row (order[r] in 0..K-1, or -1), which is the row index it would occupy
-// after the reference's swaps.  Returns mu_null[n] = sum_r alpha[order[r]] * V[r][n] = (Nc @ alpha)[n].
-template <typename T, int N, int K>
-__device__ __forceinline__ void rref_apply(T (&nb)[N][K], const T (&alpha)[K], T tol, T (&out)[N]) {
-    int order[K];
+// "Chart" of the null basis: (Nc @ alpha) with Nc = rref(nb, row_vectors=False, tol) as the reference computes it
+// (null_space_coordinate.py:40-79 called from atacom.py:128,131) -- WITHOUT running Gauss-Jordan over all N columns.
+//
+// The reference eliminates on V = nb^T (K x N), column by column: the best remaining pivot p of column j is tested
+// against tol; p <= tol zeroes the column in the unused rows and moves on, otherwise the pivot row is scaled and
+// eliminated from every row, over all columns >= j.  Observations that make this cheap:
+//   * row operations act on every column independently, so column j of the running matrix is  T V[:, j]  with T
+//     the K x K product of the elimination steps taken so far (a rank-1 update per pivot);
+//   * a pivot column ends as a unit vector:            (Nc alpha)[j] = alpha[#pivots before it];
+//   * a skipped column is frozen at the moment it is skipped (its entries in the not-yet-used rows are zeroed, so
+//     no later pivot row can change it):               (Nc alpha)[j] = sum over USED rows of alpha~[r] v[r];
+//   * a column reached after the K-th pivot is just  T_final V[:, j]  -- the same formula with every row used.
+// So one uniform step per column -- v = T V[:, j] (K^2 FMA), arg-max over unused rows, one dot product -- plus a
+// K^2 rank-1 update of T on the (at most K) columns that pivot, guarded by a wave-uniform ballot.  ~1.4 k
+// instructions for 5 x 17 instead of ~4.3 k for the literal Gauss-Jordan, identical results in exact arithmetic
+// (the tolerance test sees the same values: the candidates of column j are T V[:, j] restricted to unused rows).
+template <typename T, int K>
+struct ChartState {
+    T Tm[K][K];      // accumulated elimination steps
+    T at[K];         // alpha~[r] = alpha[order of row r] for used rows, 0 for unused rows
     bool used[K];
+    int cnt;
+    T anext;         // alpha[cnt]
+    __device__ __forceinline__ void init(const T (&alpha)[K]) {
 #pragma unroll
-    for (int r = 0; r < K; ++r) { order[r] = -1; used[r] = false; }
-    int cnt = 0;
+        for (int r = 0; r < K; ++r) {
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const bool active = cnt < K;
-        if (__builtin_amdgcn_ballot_w64(active) != 0ull) {      // wave-uniform early-out
-            T p = T(-1);
-            int kk = 0;
+            for (int c = 0; c < K; ++c) Tm[r][c] = (r == c) ? T(1) : T(0);
+            at[r] = T(0);
+            used[r] = false;
+        }
+        cnt = 0;
+        anext = alpha[0];
+    }
+    // examine one column (raw entries col[K]); returns its (Nc alpha) value
+    __device__ __forceinline__ T examine(const T (&col)[K], const T (&alpha)[K], T tol) {
+        T v[K];
 #pragma unroll
-            for (int r = 0; r < K; ++r) {
-                const T av = used[r] ? T(-1) : num<T>::abs(nb[j][r]);
-                const bool gt = av > p;                          // strict: keeps the first maximum
-                p = gt ? av : p;
-                kk = gt ? r : kk;
+        for (int r = 0; r < K; ++r) {
+            T acc = Tm[r][0] * col[0];
+#pragma unroll
+            for (int c = 1; c < K; ++c) acc = num<T>::fma(Tm[r][c], col[c], acc);
+            v[r] = acc;
+        }
+        T p = T(-1), pv = T(1), dotv = T(0);
+        int kk = 0;
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const T av = used[r] ? T(-1) : num<T>::abs(v[r]);
+            const bool gt = av > p;                              // strict: first maximum, like np.argmax
+            p = gt ? av : p;
+            kk = gt ? r : kk;
+            pv = gt ? v[r] : pv;
+            dotv = num<T>::fma(at[r], v[r], dotv);
+        }
+        const bool piv = (cnt < K) && (p > tol);
+        const T result = piv ? anext : dotv;
+        if (__builtin_amdgcn_ballot_w64(piv) != 0ull) {           // wave-uniform: only ~K columns ever pivot
+            const T invp = piv ? num<T>::rcp(pv) : T(0);         // lanes that do not pivot apply the identity
+            T rk[K], d[K];
+#pragma unroll
+            for (int c = 0; c < K; ++c) {
+                T t = T(0);
+#pragma unroll
+                for (int r = 0; r < K; ++r) t = (r == kk) ? Tm[r][c] : t;
+                rk[c] = t * invp;
             }
-            const bool piv = active && (p > tol);
-            const bool skip = active && !piv;
-            // pivot value and reciprocal (0 on lanes that do not pivot, so they are left untouched)
-            T pj = T(0);
-#pragma unroll
-            for (int r = 0; r < K; ++r) pj = (r == kk) ? nb[j][r] : pj;
-            const T inv = piv ? num<T>::rcp(pj) : T(0);
-            T f[K];
 #pragma unroll
             for (int r = 0; r < K; ++r) {
                 const bool is_p = piv && (r == kk);
-                f[r] = (piv && !is_p) ? nb[j][r] : T(0);
-                // column j itself: pivot row -> 1, other rows -> 0 (exactly), skipped -> 0 on unused rows
-                const T cur = nb[j][r];
-                nb[j][r] = is_p ? T(1) : ((piv || (skip && !used[r])) ? T(0) : cur);
-            }
-#pragma unroll
-            for (int c = j + 1; c < N; ++c) {
-                T pr = T(0);
-#pragma unroll
-                for (int r = 0; r < K; ++r) pr = (r == kk) ? nb[c][r] : pr;
-                pr *= inv;
-#pragma unroll
-                for (int r = 0; r < K; ++r) {
-                    const bool is_p = piv && (r == kk);
-                    const T upd = num<T>::fma(-f[r], pr, nb[c][r]);
-                    nb[c][r] = is_p ? pr : upd;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < K; ++r) {
-                const bool is_p = piv && (r == kk);
-                order[r] = is_p ? cnt : order[r];
+                d[r] = is_p ? v[r] - T(1) : v[r];
+                at[r] = is_p ? anext : at[r];
                 used[r] = used[r] || is_p;
             }
+#pragma unroll
+            for (int r = 0; r < K; ++r)
+#pragma unroll
+                for (int c = 0; c < K; ++c) Tm[r][c] = num<T>::fma(-d[r], rk[c], Tm[r][c]);
             cnt += piv ? 1 : 0;
+            T an = alpha[K - 1];
+#pragma unroll
+            for (int k = K - 2; k >= 0; --k) an = (cnt == k) ? alpha[k] : an;
+            anext = an;
         }
+        return result;
     }
-    T ar[K];
+};
+
+template <typename T, int N, int K>
+__device__ __forceinline__ void rref_apply(T (&nb)[N][K], const T (&alpha)[K], T tol, T (&out)[N]) {
+    ChartState<T, K> st;
+    st.init(alpha);
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
-        T v = T(0);
-#pragma unroll
-        for (int k = 0; k < K; ++k) v = (order[r] == k) ? alpha[k] : v;
-        ar[r] = v;
-    }
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        T v = T(0);
-#pragma unroll
-        for (int r = 0; r < K; ++r) v = num<T>::fma(ar[r], nb[n][r], v);
-        out[n] = v;
-    }
+    for (int j = 0; j < N; ++j) out[j] = st.examine(nb[j], alpha, tol);
 }
 
 }  // namespace atacom

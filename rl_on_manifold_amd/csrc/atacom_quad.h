@@ -183,7 +183,12 @@ __device__ __forceinline__ void bidiag_solve_null_quad(T (&a)[M][(N + 3) / 4], T
     });
 }
 
-// rref chart + Nc @ alpha on the column-split null basis (see rref_apply in atacom_linalg.h).
+// Chart (rref + Nc @ alpha) on the column-split null basis.  Measured on MI355X: for the
+// quad mapping the literal Gauss-Jordan below beats the T-matrix formulation used by the one-lane mapping
+// (atacom_linalg.h: ChartState) -- the latter is a serial dependency chain per column, whereas here the K x S
+// updates of a pivot step are independent across slots and lanes and a lone wave is latency-, not issue-bound.
+// Semantics: null_space_coordinate.py:40-79 with row_vectors=False; rows are not physically swapped, each row
+// records the order in which it became a pivot row.
 // out[slot] = (Nc @ alpha)[4*slot + lq].
 template <typename T, int N, int K>
 __device__ __forceinline__ void rref_apply_quad(T (&nb)[(N + 3) / 4][K], const T (&alpha)[K], T tol,
