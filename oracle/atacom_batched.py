@@ -16,7 +16,7 @@ import numpy as np
 
 from . import robots
 from .atacom_scalar import (ENV_CIRCLE, ENV_PLANAR, ENV_IIWA, TABLE_LENGTH, TABLE_WIDTH, GOAL_WIDTH,
-                            MALLET_RADIUS, UNIVERSAL_HEIGHT, HIT_RANGE, GOAL_POS)
+                            MALLET_RADIUS, PUCK_RADIUS, UNIVERSAL_HEIGHT, HIT_RANGE, GOAL_POS, E_MALLET, E_RIM)
 
 
 def _diag_batch(x):
@@ -263,6 +263,7 @@ class BatchedAtacomEnv:
             q_ctl, dq_ctl = self.q.copy(), self.dq.copy()
             q_sim, dq_sim = self.q.copy(), self.dq.copy()
             terms = constraint_terms(sp, q_ctl, dq_ctl)
+            m0 = mallet_xy_world(sp, self.q)
             for _ in range(sp.substeps):
                 if not sp.hold_q:
                     q_ctl, dq_ctl = q_sim.copy(), dq_sim.copy()
@@ -272,8 +273,10 @@ class BatchedAtacomEnv:
                 ddq = self.acc_truncation(dq_ctl, mu[:, :nq])
                 dq_sim = np.clip(dq_sim + ddq * sp.dt, -1.5 * sp.vel_max, 1.5 * sp.vel_max)
                 q_sim = q_sim + dq_sim * sp.dt
-                self._puck_substep()
             self.q, self.dq = q_sim, dq_sim
+            m1 = mallet_xy_world(sp, self.q)
+            for k in range(sp.substeps):
+                self._puck_substep(m0 + (m1 - m0) * ((k + 1) / sp.substeps), (m1 - m0) / (sp.substeps * sp.dt))
             absorbing = self._is_absorbing()
             reward = self._reward(alpha, absorbing)
             fun, _, _ = constraint_terms(sp, self.q, np.zeros_like(self.q))
@@ -284,12 +287,34 @@ class BatchedAtacomEnv:
         self.t += 1
         return self.observation(), reward, absorbing, {}
 
-    def _puck_substep(self):
+    def _puck_substep(self, mallet, mallet_vel):
+        """Batched version of atacom_scalar.ScalarAtacomEnv._puck_substep (contact model of this build, row N1)."""
         sp = self.spec
-        self.puck[:, 0:3] += self.puck[:, 3:6] * sp.dt
-        v = np.hypot(self.puck[:, 3], self.puck[:, 4])
+        pk = self.puck
+        pk[:, 0:3] += pk[:, 3:6] * sp.dt
+        d = pk[:, 0:2] - mallet
+        dist = np.hypot(d[:, 0], d[:, 1])
+        R = PUCK_RADIUS + MALLET_RADIUS
+        hit = dist < R
+        safe = np.where(dist > 0, dist, 1.0)
+        n = np.where((dist > 0)[:, None], d / safe[:, None], np.array([1.0, 0.0]))
+        vrel = ((pk[:, 3:5] - mallet_vel) * n).sum(-1)
+        imp = hit & (vrel < 0)
+        pk[:, 3:5] = np.where(imp[:, None], pk[:, 3:5] - ((1 + E_MALLET) * vrel)[:, None] * n, pk[:, 3:5])
+        pk[:, 0:2] = np.where(hit[:, None], mallet + n * R, pk[:, 0:2])
+        ylim = TABLE_WIDTH / 2 - PUCK_RADIUS
+        oy = np.abs(pk[:, 1]) > ylim
+        sg = np.sign(pk[:, 1])
+        pk[:, 1] = np.where(oy, sg * (2 * ylim - np.abs(pk[:, 1])), pk[:, 1])
+        pk[:, 4] = np.where(oy & (pk[:, 4] * sg > 0), -E_RIM * pk[:, 4], pk[:, 4])
+        xlim = TABLE_LENGTH / 2 - PUCK_RADIUS
+        ox = (np.abs(pk[:, 0]) > xlim) & (np.abs(pk[:, 1]) >= GOAL_WIDTH)
+        sg = np.sign(pk[:, 0])
+        pk[:, 0] = np.where(ox, sg * (2 * xlim - np.abs(pk[:, 0])), pk[:, 0])
+        pk[:, 3] = np.where(ox & (pk[:, 3] * sg > 0), -E_RIM * pk[:, 3], pk[:, 3])
+        v = np.hypot(pk[:, 3], pk[:, 4])
         new_hit = (~self.has_hit) & (v > 0.1)
-        self.vel_hit_x = np.where(new_hit, self.puck[:, 3], self.vel_hit_x)
+        self.vel_hit_x = np.where(new_hit, pk[:, 3], self.vel_hit_x)
         self.has_hit |= new_hit
 
     def _is_absorbing(self):

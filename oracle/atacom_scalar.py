@@ -27,6 +27,8 @@ TABLE_LENGTH, TABLE_WIDTH, GOAL_WIDTH = 1.96, 1.02, 0.25
 PUCK_RADIUS, MALLET_RADIUS, UNIVERSAL_HEIGHT = 0.03165, 0.05, 0.1505
 HIT_RANGE = np.array([[-0.6, -0.2], [-0.4, 0.4]])      # env_hitting.py:11
 GOAL_POS = np.array([0.98, 0.0])                        # env_hitting.py:12
+# contact model of this build (row N1; Bullet's is unpinned): restitution of mallet / rim contacts
+E_MALLET, E_RIM = 0.8, 0.8
 
 
 @dataclass
@@ -266,6 +268,7 @@ class ScalarAtacomEnv:
         else:
             q_ctl, dq_ctl = self.q.copy(), self.dq.copy()       # held copies (quirk Q1)
             q_sim, dq_sim = self.q.copy(), self.dq.copy()
+            m0 = mallet_xy_world(sp, self.q)                     # mallet at the start of the env step
             for _ in range(sp.substeps):
                 if not sp.hold_q:
                     q_ctl, dq_ctl = q_sim.copy(), dq_sim.copy()
@@ -276,9 +279,13 @@ class ScalarAtacomEnv:
                 # clamp at 1.5 x the URDF limit (iiwa_hit_atacom.py:48-50, atacom_air_hockey.py:49-54)
                 dq_sim = np.clip(dq_sim + ddq * sp.dt, -1.5 * sp.vel_max, 1.5 * sp.vel_max)
                 q_sim = q_sim + dq_sim * sp.dt
-                self._puck_substep(q_sim, dq_sim)
                 dbg.append(mu)
             self.q, self.dq = q_sim, dq_sim                      # atacom.py:111-112
+            # puck: the arm is kinematic w.r.t. the puck (no reaction), so the sub-steps of the puck run after
+            # the arm's, against a mallet moving uniformly from m0 to m1 over the env step
+            m1 = mallet_xy_world(sp, self.q)
+            for k in range(sp.substeps):
+                self._puck_substep(m0 + (m1 - m0) * ((k + 1) / sp.substeps), (m1 - m0) / (sp.substeps * sp.dt))
             absorbing = self._is_absorbing()
             reward = self._reward(alpha, absorbing)
             c_i = origin_constraints(sp, self.q)                 # atacom.py:201-205
@@ -287,15 +294,41 @@ class ScalarAtacomEnv:
         out = (self.observation(), reward, absorbing, {})
         return out + (dbg,) if return_debug else out
 
-    # -- puck: frictionless free motion; contact model is the "next" row N1
-    def _puck_substep(self, q_sim, dq_sim):
+    # -- puck: 2-D disc on a frictionless table, kinematic mallet, elastic rims with a goal mouth (row N1).
+    #    PyBullet's contact solver is unpinned; this is the model of this build.
+    def _puck_substep(self, mallet, mallet_vel):
         sp = self.spec
-        self.puck[0:3] = self.puck[0:3] + self.puck[3:6] * sp.dt
+        pk = self.puck
+        pk[0:3] = pk[0:3] + pk[3:6] * sp.dt
+        # mallet contact: impulse along the centre line if approaching, then push the puck out of the overlap
+        d = pk[0:2] - mallet
+        dist = np.hypot(d[0], d[1])
+        R = PUCK_RADIUS + MALLET_RADIUS
+        if dist < R:
+            n = d / dist if dist > 0 else np.array([1.0, 0.0])
+            vrel = (pk[3:5] - mallet_vel) @ n
+            if vrel < 0:
+                pk[3:5] = pk[3:5] - (1 + E_MALLET) * vrel * n
+            pk[0:2] = mallet + n * R
+        # side rims (y)
+        ylim = TABLE_WIDTH / 2 - PUCK_RADIUS
+        if abs(pk[1]) > ylim:
+            sgn = np.sign(pk[1])
+            pk[1] = sgn * (2 * ylim - abs(pk[1]))
+            if pk[4] * sgn > 0:
+                pk[4] = -E_RIM * pk[4]
+        # end rims (x) except in the goal mouth |y| < goal half-width (env_hitting.py:44-45)
+        xlim = TABLE_LENGTH / 2 - PUCK_RADIUS
+        if abs(pk[0]) > xlim and abs(pk[1]) >= GOAL_WIDTH:
+            sgn = np.sign(pk[0])
+            pk[0] = sgn * (2 * xlim - abs(pk[0]))
+            if pk[3] * sgn > 0:
+                pk[3] = -E_RIM * pk[3]
         if not self.has_hit:                                     # env_hitting.py:80-85
-            v = np.hypot(self.puck[3], self.puck[4])
+            v = np.hypot(pk[3], pk[4])
             if v > 0.1:
                 self.has_hit = True
-                self.vel_hit_x = self.puck[3]
+                self.vel_hit_x = pk[3]
 
     def _is_absorbing(self):
         # env_base.py:182-194 + env_hitting.py:71-78

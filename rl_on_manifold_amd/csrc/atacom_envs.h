@@ -40,6 +40,8 @@ struct Params {
     T goal_x, goal_y, goal_w;  // goal position / half width
     T ee_height;               // universal_height 0.1505
     T z4_min, z7_min;          // 0.36, 0.25  (iiwa_hit_atacom.py:104-105)
+    T puck_r, mallet_r;        // 0.03165, 0.05 (env_base.py:157-158)
+    T e_mallet, e_rim;         // restitution of the contact model of this build
 };
 
 // ---------------------------------------------------------------------------------------- circle

@@ -147,6 +147,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
         out.log_dq = num<T>::max(num<T>::abs(st.dq[0]), num<T>::abs(st.dq[1])) - T(1);
     }
     T qc[NQ], dqc[NQ];          // what the controller sees (held over the sub-steps when hold_q)
+    T m0x = T(0), m0y = T(0);   // mallet position at the start of the env step
     T A[NC][NQ], psi[NC], c0[NC];
     constexpr int SQ = (NN + 3) / 4;
     T Aq[NC][SQ];              // LANES == 4: this lane's columns of [K J | 0]
@@ -157,6 +158,12 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
             for (int i = 0; i < NQ; ++i) { qc[i] = st.q[i]; dqc[i] = st.dq[i]; }
             T fun[NC], J[NC][NQ], bst[NC];
             constraint_terms(E{}, P, qc, dqc, fun, J, bst);
+            if (E::PUCK && sub == 0) {
+                // mallet (= tip) xy at the start of the step, recovered from the table constraints
+                // g1 = -x - bx, g3 = y - by  (rows NF, NF+2)
+                m0x = -(fun[NF < NC ? NF : 0] + P.table_bx);
+                m0y = fun[NF + 2 < NC ? NF + 2 : 0] + P.table_by;
+            }
 #pragma unroll
             for (int r = 0; r < NC; ++r) {
                 T jdq = T(0);
@@ -250,13 +257,6 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 st.dq[i] = num<T>::min(num<T>::max(num<T>::fma(ddq[i], P.dt, st.dq[i]), -vlim), vlim);
                 st.q[i] = num<T>::fma(st.dq[i], P.dt, st.q[i]);
             }
-            // puck: free motion; has_hit latch (env_hitting.py:80-85)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) st.puck[i] = num<T>::fma(st.puck[3 + i], P.dt, st.puck[i]);
-            const T pv2 = num<T>::fma(st.puck[3], st.puck[3], st.puck[4] * st.puck[4]);
-            const bool new_hit = (st.has_hit == 0) && (pv2 > T(0.01));
-            st.vel_hit_x = new_hit ? st.puck[3] : st.vel_hit_x;
-            st.has_hit = new_hit ? 1 : st.has_hit;
         }
     }
     if (E::ID == 0) {
@@ -266,6 +266,53 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
     } else {
         T fun[NC], mxy[2];
         constraint_fun(E{}, P, st.q, fun, mxy);
+        // ---- puck (row N1): the arm is kinematic w.r.t. the puck, so the puck's sub-steps run after the arm's,
+        // against a mallet moving uniformly from (m0x, m0y) to mxy over the env step.  Frictionless disc,
+        // impulse + push-out at the mallet, elastic rims, open goal mouths (env_hitting.py:44-45).
+        {
+            const T inv_n = num<T>::rcp((T)P.substeps);
+            const T ux = (mxy[0] - m0x) * inv_n / P.dt, uy = (mxy[1] - m0y) * inv_n / P.dt;
+            const T R = P.puck_r + P.mallet_r;
+            const T ylim = P.table_hy - P.puck_r, xlim = P.table_hx - P.puck_r;
+#pragma unroll 1
+            for (int k = 0; k < P.substeps; ++k) {
+                const T fr = (T)(k + 1) * inv_n;
+                const T mx = num<T>::fma(mxy[0] - m0x, fr, m0x), my = num<T>::fma(mxy[1] - m0y, fr, m0y);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) st.puck[i] = num<T>::fma(st.puck[3 + i], P.dt, st.puck[i]);
+                const T dxm = st.puck[0] - mx, dym = st.puck[1] - my;
+                const T dist = num<T>::sqrt(num<T>::fma(dxm, dxm, dym * dym));
+                const bool hit = dist < R;
+                const bool pos = dist > T(0);
+                const T idist = pos ? num<T>::rcp(dist) : T(0);
+                const T nx = pos ? dxm * idist : T(1), ny = pos ? dym * idist : T(0);
+                const T vrel = (st.puck[3] - ux) * nx + (st.puck[4] - uy) * ny;
+                const bool imp = hit && (vrel < T(0));
+                const T jimp = imp ? (T(1) + P.e_mallet) * vrel : T(0);
+                st.puck[3] = num<T>::fma(-jimp, nx, st.puck[3]);
+                st.puck[4] = num<T>::fma(-jimp, ny, st.puck[4]);
+                st.puck[0] = hit ? num<T>::fma(nx, R, mx) : st.puck[0];
+                st.puck[1] = hit ? num<T>::fma(ny, R, my) : st.puck[1];
+                {   // side rims
+                    const T ay = num<T>::abs(st.puck[1]);
+                    const bool oy = ay > ylim;
+                    const T sg = st.puck[1] > T(0) ? T(1) : (st.puck[1] < T(0) ? T(-1) : T(0));
+                    st.puck[1] = oy ? sg * (T(2) * ylim - ay) : st.puck[1];
+                    st.puck[4] = (oy && st.puck[4] * sg > T(0)) ? -P.e_rim * st.puck[4] : st.puck[4];
+                }
+                {   // end rims, open in the goal mouth
+                    const T ax = num<T>::abs(st.puck[0]);
+                    const bool ox = (ax > xlim) && (num<T>::abs(st.puck[1]) >= P.goal_w);
+                    const T sg = st.puck[0] > T(0) ? T(1) : (st.puck[0] < T(0) ? T(-1) : T(0));
+                    st.puck[0] = ox ? sg * (T(2) * xlim - ax) : st.puck[0];
+                    st.puck[3] = (ox && st.puck[3] * sg > T(0)) ? -P.e_rim * st.puck[3] : st.puck[3];
+                }
+                const T pv2k = num<T>::fma(st.puck[3], st.puck[3], st.puck[4] * st.puck[4]);
+                const bool new_hit = (st.has_hit == 0) && (pv2k > T(0.01));      // env_hitting.py:80-85
+                st.vel_hit_x = new_hit ? st.puck[3] : st.vel_hit_x;
+                st.has_hit = new_hit ? 1 : st.has_hit;
+            }
+        }
         // absorbing: env_base.py:182-194 + env_hitting.py:71-78
         const T pv2 = num<T>::fma(st.puck[3], st.puck[3], st.puck[4] * st.puck[4]);
         bool ab = (num<T>::abs(st.puck[0]) > P.table_hx) || (num<T>::abs(st.puck[1]) > P.table_hy);

@@ -28,6 +28,7 @@ static Params<T> make_params(const atacom_config& c) {
     P.table_hx = (T)(table_l / 2); P.table_hy = (T)(table_w / 2);
     P.goal_x = (T)0.98; P.goal_y = (T)0.0; P.goal_w = (T)0.25;
     P.ee_height = (T)0.1505; P.z4_min = (T)0.36; P.z7_min = (T)0.25;
+    P.puck_r = (T)0.03165; P.mallet_r = (T)mallet_r; P.e_mallet = (T)0.8; P.e_rim = (T)0.8;
     return P;
 }
 

@@ -135,6 +135,55 @@ def test_env_step_teacher_forced_against_oracle(name, dt, lanes):
     assert np.allclose(c_dev, c_or, atol=1e-8 if dt == 'f64' else 2e-3)
 
 
+@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('dt', ['f64', 'f32'])
+@pytest.mark.parametrize('name', ['planar', 'iiwa'])
+def test_puck_contact_model_against_oracle(name, dt, lanes):
+    """Row N1 (this build's contact model, Bullet being unpinned): mallet impulses, rim bounces, goal mouth, has_hit
+    latch, hitting reward and termination -- HIP vs oracle from identical injected states."""
+    spec = SPECS[name]()
+    B, T = 512, 30
+    env = _env(name, B, dt, lanes_per_env=lanes)
+    nq, ng = spec.dim_q, spec.n_g
+    st0 = env.get_state().cpu().numpy().astype(np.float64)
+    rng = np.random.default_rng(21)
+    init_q = st0[:, :nq] + rng.normal(0, 0.03, (B, nq))
+    mal = ob.mallet_xy_world(spec, init_q)
+    puck = np.zeros((B, 6))
+    third = B // 3
+    ang = rng.uniform(-1.2, 1.2, B)
+    puck[:, 0] = mal[:, 0] + 0.1 * np.cos(ang)            # just in front of the mallet, moving towards it
+    puck[:, 1] = mal[:, 1] + 0.1 * np.sin(ang)
+    puck[:, 3] = -rng.uniform(0.0, 1.0, B) * np.cos(ang)
+    puck[:, 4] = -rng.uniform(0.0, 1.0, B) * np.sin(ang)
+    puck[third:2 * third, 0] = rng.uniform(0.6, 0.93, third)             # fast pucks near the far end: rims + goal
+    puck[third:2 * third, 1] = rng.uniform(-0.45, 0.45, third)
+    puck[third:2 * third, 3] = rng.uniform(1.0, 4.0, third)
+    puck[third:2 * third, 4] = rng.uniform(-3.0, 3.0, third)
+    o = ob.BatchedAtacomEnv(spec, B, init_q=init_q, init_puck=puck)
+    errs, n_abs, n_goal, n_hit = [], 0, 0, 0
+    for t in range(T):
+        a = rng.uniform(-1.0, 1.0, (B, spec.n_null))
+        a[:third, 0] = 1.0
+        env.set_state(_full_state(env, o))
+        obs, r, ab, info = env.step(a)
+        oo, orr, oab, _ = o.step(a)
+        st = env.get_state().cpu().numpy()
+        e = np.maximum(np.abs(obs.cpu().numpy() - oo).max(1), np.abs(r.cpu().numpy() - orr))
+        e = np.maximum(e, np.abs(st[:, 2 * nq + ng + 7] - o.r_hit))
+        e = np.maximum(e, np.abs(st[:, 2 * nq + ng + 8] - o.vel_hit_x))
+        errs.append(e)
+        assert (ab.cpu().numpy() == oab).all() and (st[:, 2 * nq + ng + 6].astype(bool) == o.has_hit).all()
+        n_abs += oab.sum(); n_goal += (orr > 70).sum(); n_hit += o.has_hit.sum()
+        o.reset(oab)                                     # finished episodes restart (both sides via set_state)
+    errs = np.array(errs)
+    assert n_abs > 0 and n_goal > 0 and n_hit > 0          # the scenario really exercises contacts, goals, hits
+    if dt == 'f64':
+        assert errs.max() < 1e-8, errs.max()
+    else:
+        assert np.median(errs) < 2e-5 and (errs < 2e-3).mean() >= 0.99, (np.median(errs), (errs < 2e-3).mean())
+
+
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 def test_circle_reference_trajectories_through_capi(golden, dt):
     """G4: the reference's own CircleEnvAtacom trajectories, replayed step by step through the HIP path."""
@@ -175,6 +224,8 @@ def test_generic_wrapper_reference_trajectories_through_capi(golden, name, dt, l
     nq, ng = spec.dim_q, spec.n_g
     env = _env(name, n, dt, lanes_per_env=lanes)
     full = env.get_state().cpu().numpy().astype(np.float64)
+    # the golden runs had a static puck: park this build's puck far from the arm, compare the arm columns
+    full[:, 2 * nq + ng:2 * nq + ng + 6] = [0.8, 0.4, 0, 0, 0, 0]
     errs = []
     for t in range(T):
         q, dq, ss = (init[:, :nq], init[:, nq:], s0) if t == 0 else (obs[:, t - 1, 6:6 + nq], obs[:, t - 1, 6 + nq:], s[:, t - 1])
@@ -182,7 +233,7 @@ def test_generic_wrapper_reference_trajectories_through_capi(golden, name, dt, l
         env.set_state(full)
         o, r, ab, _ = env.step(acts[:, t])
         s_dev = env.get_state().cpu().numpy()[:, 2 * nq:2 * nq + ng]
-        errs.append(np.maximum(np.abs(o.cpu().numpy() - obs[:, t]).max(1), np.abs(s_dev - s[:, t]).max(1)))
+        errs.append(np.maximum(np.abs(o.cpu().numpy()[:, 6:] - obs[:, t, 6:]).max(1), np.abs(s_dev - s[:, t]).max(1)))
     errs = np.array(errs)
     if dt == 'f64':
         assert errs.max() < 1e-8, errs.max()
