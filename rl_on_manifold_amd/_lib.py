@@ -47,6 +47,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # The process must use ONE HIP runtime.  PyTorch-ROCm bundles its own libamdhip64; if libatacom_hip.so were
+    # dlopen'ed first it would pull in /opt/rocm's copy and the two runtimes would fight over the device (observed:
+    # hipGetDeviceCount -> "no ROCm-capable device").  Importing torch first makes the .so bind to torch's runtime.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # noqa: BLE001  (a pure-C consumer of the ABI does not need torch)
+        pass
     if not os.path.exists(LIB_PATH):
         raise AtacomError("libatacom_hip.so is not built (%s). Run `python -m rl_on_manifold_amd.build` -- "
                           "there is no CPU fallback." % LIB_PATH)
