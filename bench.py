@@ -153,6 +153,24 @@ def main():
     torch.cuda.synchronize(dev)
     roll_rate = n_roll * T * B / (time.perf_counter() - t1)
 
+    # ---- secondary (row N2): the same rollout with the actor MLP (18-64-64-5, random weights) + Gaussian noise
+    # evaluated inside the kernel -- one launch per 120-step collection phase, no per-step host round trip
+    pol_rate = None
+    if args.env != 'circle':
+        from rl_on_manifold_amd import MlpPolicy
+        gw = torch.Generator(device='cpu'); gw.manual_seed(0)
+        Wts = [torch.randn(64, D, generator=gw) * 0.2, torch.zeros(64), torch.randn(64, 64, generator=gw) * 0.1,
+             torch.zeros(64), torch.randn(k, 64, generator=gw) * 0.1, torch.zeros(k)]
+        pol = MlpPolicy(*Wts, std=torch.full((k,), 0.5))
+        eps = torch.randn((T, B, k), device=dev, generator=gen)
+        env.rollout_policy(pol, T, noise=eps)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for _ in range(n_roll):
+            env.rollout_policy(pol, T, noise=eps)
+        torch.cuda.synchronize(dev)
+        pol_rate = n_roll * T * B / (time.perf_counter() - t2)
+
     result = None
     if rank == 0:
         value = world * B * K / elapsed
@@ -178,6 +196,7 @@ def main():
                        'parallelism': 'env-shard x%d, no data-path collective' % world},
             'max_abs_c': c_max, 'c_avg': c_avg, 'c_dq_max': c_dq_max,
             'rollout_kernel_env_steps_per_s_per_gpu': roll_rate,
+            'policy_rollout_kernel_env_steps_per_s_per_gpu': pol_rate,
             'roofline': {'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': algo_bytes, 'kernel_ms': kern_ms,

@@ -114,6 +114,28 @@ int atacom_step(atacom_handle* h, const void* d_action, void* d_obs, void* d_rew
 int atacom_rollout(atacom_handle* h, int32_t n_steps, const void* d_actions, void* d_obs, void* d_next_obs,
                    void* d_reward, uint8_t* d_absorbing, uint8_t* d_last, void* stream);
 
+/* Row N2 -- rollout with the actor network evaluated inside the kernel.  The network is the 2-hidden-layer MLP every
+ * reference training script builds (examples/network.py:8-36,39-68,266-293: Linear(n_in,64)-ReLU-Linear(64,64)-ReLU-
+ * Linear(64,n_out)); weights in torch.nn.Linear layout W[out][in], element type = the handle's dtype, device memory.
+ * action = MLP((obs - obs_shift) * obs_scale) + std * noise   (MinMaxPreprocessor + GaussianTorchPolicy of
+ * examples/iiwa_air_hockey_exp.py:32-34,138-146); d_noise [n_steps, batch, n_out] is supplied by the caller (NULL = 0). */
+typedef struct atacom_mlp {
+    int32_t struct_size;  /* = sizeof(atacom_mlp) */
+    int32_t n_in;         /* must equal obs_dim */
+    int32_t hidden;       /* units of both hidden layers; 64 supported */
+    int32_t n_out;        /* must equal n_null */
+    int32_t activation;   /* 0 = ReLU, 1 = tanh */
+    int32_t reserved;
+    const void *W1, *b1, *W2, *b2, *W3, *b3;
+    const void *obs_shift, *obs_scale; /* [n_in], may be NULL (identity) */
+    const void *std;                   /* [n_out], may be NULL (deterministic) */
+} atacom_mlp;
+
+/* Like atacom_rollout, with d_actions [n_steps, batch, n_out] an OUTPUT (the actions the policy drew). */
+int atacom_rollout_mlp(atacom_handle* h, int32_t n_steps, const atacom_mlp* net, const void* d_noise, void* d_obs,
+                       void* d_next_obs, void* d_actions, void* d_reward, uint8_t* d_absorbing, uint8_t* d_last,
+                       void* stream);
+
 /* get_constraints_logs (atacom.py:207-216; circle_base.py:109-115): out = {c_avg, c_max, c_dq_max} over every
  * (env, step) logged since the last clear.  Synchronises `stream`. */
 int atacom_get_stats(atacom_handle* h, double out[3], int32_t clear, void* stream);

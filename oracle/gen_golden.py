@@ -18,6 +18,7 @@ Golden sets:
                     sub-steps per step (reproduces the zero-order hold of q, dq -- quirk Q1)
   G6 tables         acc_truncation and _compute_slack_variables
   G7 logs           get_constraints_logs aggregation
+  G8 policy         the reference's actor networks (examples/network.py) forward() on random inputs (row N2)
 """
 import os
 import sys
@@ -393,8 +394,35 @@ def gen_tables():
     print('tables.npz')
 
 
+def gen_policy():
+    """G8: the reference's actor networks (examples/network.py) evaluated by the reference's own forward()."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location('ref_network', '/root/reference/examples/network.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    rng = np.random.default_rng(17)
+    for name, cls, n_in, n_out in (('ppo_iiwa', mod.PPONetwork, 18, 5), ('sac_planar', mod.SACActorNetwork, 12, 3),
+                                   ('trpo_iiwa', mod.TRPONetwork, 18, 5)):
+        torch.manual_seed(123)
+        net = cls((n_in,), (n_out,), [64, 64])
+        with torch.no_grad():
+            for lin in (net._h1, net._h2, net._h3):
+                lin.bias.uniform_(-0.3, 0.3)          # torch's default bias init is small; make the test sensitive
+        x = rng.uniform(-2, 2, (32, 1, n_in)).astype(np.float32)
+        with torch.no_grad():
+            y = net(torch.from_numpy(x)).numpy()
+        for k, v in net.state_dict().items():
+            out[name + '.' + k] = v.numpy()
+        out[name + '.x'] = x[:, 0]
+        out[name + '.y'] = y
+    np.savez_compressed(os.path.join(OUT, 'policy_net.npz'), **out)
+    print('policy_net.npz', sorted(out)[:6], '...')
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    todo = sys.argv[1:] or ['nullspace', 'constraints', 'circle', 'generic', 'tables']
+    todo = sys.argv[1:] or ['nullspace', 'constraints', 'circle', 'generic', 'tables', 'policy']
     for name in todo:
         globals()['gen_' + name]()

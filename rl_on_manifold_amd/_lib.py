@@ -14,7 +14,7 @@ ENV_CIRCLE, ENV_PLANAR, ENV_IIWA = 0, 1, 2
 F32, F64 = 0, 1
 MAX_C, MAX_Q = 12, 6
 
-EXPORTS = ['atacom_default_config', 'atacom_get_dims', 'atacom_create', 'atacom_destroy', 'atacom_reset',
+EXPORTS = ['atacom_rollout_mlp', 'atacom_default_config', 'atacom_get_dims', 'atacom_create', 'atacom_destroy', 'atacom_reset',
            'atacom_step', 'atacom_rollout', 'atacom_get_stats', 'atacom_get_state', 'atacom_set_state',
            'atacom_nullspace', 'atacom_constraint_terms', 'atacom_last_error', 'atacom_version']
 
@@ -28,6 +28,15 @@ class AtacomConfig(C.Structure):
                 ('K', C.c_double * MAX_C), ('Kc', C.c_double * MAX_C), ('vel_max', C.c_double * MAX_Q),
                 ('acc_max', C.c_double * MAX_Q), ('Kq', C.c_double * MAX_Q), ('pos_limit', C.c_double * MAX_Q),
                 ('base_xy', C.c_double * 2), ('link', C.c_double * 3)]
+
+
+class AtacomMlp(C.Structure):
+    """Mirror of `atacom_mlp` (include/atacom_hip.h)."""
+    _fields_ = [('struct_size', C.c_int32), ('n_in', C.c_int32), ('hidden', C.c_int32), ('n_out', C.c_int32),
+                ('activation', C.c_int32), ('reserved', C.c_int32),
+                ('W1', C.c_void_p), ('b1', C.c_void_p), ('W2', C.c_void_p), ('b2', C.c_void_p),
+                ('W3', C.c_void_p), ('b3', C.c_void_p), ('obs_shift', C.c_void_p), ('obs_scale', C.c_void_p),
+                ('std', C.c_void_p)]
 
 
 class AtacomDims(C.Structure):
@@ -66,6 +75,7 @@ def load():
     lib.atacom_reset.argtypes = [vp, u8p, vp, vp, vp]
     lib.atacom_step.argtypes = [vp, vp, vp, vp, u8p, u8p, vp]
     lib.atacom_rollout.argtypes = [vp, i32, vp, vp, vp, vp, u8p, u8p, vp]
+    lib.atacom_rollout_mlp.argtypes = [vp, i32, C.POINTER(AtacomMlp), vp, vp, vp, vp, vp, u8p, u8p, vp]
     lib.atacom_get_stats.argtypes = [vp, C.POINTER(C.c_double * 3), i32, vp]
     lib.atacom_get_state.argtypes = [vp, vp, vp]
     lib.atacom_set_state.argtypes = [vp, vp, vp]

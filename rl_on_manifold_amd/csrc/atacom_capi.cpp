@@ -232,6 +232,30 @@ int atacom_rollout(atacom_handle* h, int32_t n_steps, const void* d_actions, voi
     return ATACOM_OK;
 }
 
+int atacom_rollout_mlp(atacom_handle* h, int32_t n_steps, const atacom_mlp* net, const void* d_noise, void* d_obs,
+                       void* d_next_obs, void* d_actions, void* d_reward, uint8_t* d_absorbing, uint8_t* d_last,
+                       void* stream) {
+    if (!h || !net) return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: null handle / network");
+    if (net->struct_size != (int32_t)sizeof(atacom_mlp))
+        return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: atacom_mlp.struct_size mismatch (ABI)");
+    if (n_steps <= 0) return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: n_steps must be positive");
+    if (net->n_in != h->ops->obs_dim || net->n_out != h->ops->nk)
+        return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: network n_in / n_out must equal obs_dim / n_null");
+    if (!net->W1 || !net->b1 || !net->W2 || !net->b2 || !net->W3 || !net->b3)
+        return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: null weight pointer");
+    if (net->activation != 0 && net->activation != 1)
+        return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: activation must be 0 (ReLU) or 1 (tanh)");
+    if (!d_obs || !d_actions || !d_reward || !d_absorbing || !d_last)
+        return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: all output buffers except d_next_obs are required");
+    HIP_TRY(hipSetDevice(h->device));
+    const int rc = h->ops->rollout_mlp(h->cfg, pick_lanes(h->cfg), n_steps, *net, h->f, h->ip, d_noise, d_obs,
+                                       d_next_obs, d_actions, d_reward, d_absorbing, d_last, (hipStream_t)stream);
+    if (rc != ATACOM_OK)
+        return fail(ATACOM_E_UNSUPPORTED, "atacom_rollout_mlp: only planar / iiwa with hidden = 64 are compiled in");
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+
 int atacom_get_stats(atacom_handle* h, double out[3], int32_t clear, void* stream) {
     if (!h || !out) return fail(ATACOM_E_INVALID, "atacom_get_stats: null argument");
     HIP_TRY(hipSetDevice(h->device));

@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include "atacom_envs.h"
 #include "atacom_quad.h"
+#include "atacom_policy.h"
 
 namespace atacom {
 
@@ -402,6 +403,66 @@ __global__ void __launch_bounds__(WAVE) k_rollout(const Params<T> P, int n_steps
         T act[E::NK];
 #pragma unroll
         for (int k = 0; k < E::NK; ++k) act[k] = actions[row * E::NK + k];
+        StepOut<T> out;
+        env_step<T, E, LANES>(P, st, act, out, lq);
+        if (lq == 0) {
+            if (next_obs) write_obs<T, E>(P, st, next_obs + row * E::OBS);
+            reward[row] = out.reward;
+            absorbing[row] = out.absorbing ? 1 : 0;
+            last[row] = out.last ? 1 : 0;
+        }
+        ssum += out.log_avg;
+        scmax = num<T>::max(scmax, out.log_max);
+        sdq = num<T>::max(sdq, out.log_dq);
+        if (P.auto_reset && out.last) load_init<T, E>(f, B, b, st);
+    }
+    if (lq != 0) return;
+    f[L::SSUM * (size_t)B + b] += ssum;
+    f[L::SCMAX * (size_t)B + b] = scmax;
+    f[L::SDQMAX * (size_t)B + b] = sdq;
+    ip[L::I_CNT * (size_t)B + b] += n_steps;
+    store_state<T, E>(f, ip, B, b, st);
+}
+
+// Row N2: rollout with the policy MLP evaluated in the kernel (atacom_policy.h).  d_actions_out receives the action
+// the policy drew (mean + std * noise, before the env's clip to [-1, 1]).
+template <typename T, typename E, int LANES, int H>
+__global__ void __launch_bounds__(WAVE) k_rollout_mlp(const Params<T> P, const MlpArgs<T> net, int n_steps,
+                                                      T* __restrict__ f, int* __restrict__ ip,
+                                                      const T* __restrict__ noise, T* __restrict__ obs,
+                                                      T* __restrict__ next_obs, T* __restrict__ actions_out,
+                                                      T* __restrict__ reward, uint8_t* __restrict__ absorbing,
+                                                      uint8_t* __restrict__ last) {
+    using L = Planes<E>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* lds = reinterpret_cast<T*>(smem);
+    mlp_stage<T, E::OBS, H, E::NK>(net, lds, threadIdx.x, WAVE);
+    const int B = P.batch;
+    const int gt = blockIdx.x * WAVE + threadIdx.x;
+    const int b = gt / LANES;
+    const int lq = gt % LANES;
+    if (b >= B) return;
+    EnvState<T, E> st;
+    load_state<T, E>(f, ip, B, b, st);
+    T ssum = T(0), scmax = f[L::SCMAX * (size_t)B + b], sdq = f[L::SDQMAX * (size_t)B + b];
+#pragma unroll 1
+    for (int t = 0; t < n_steps; ++t) {
+        const size_t row = (size_t)t * B + b;
+        T o[E::OBS];
+        write_obs<T, E>(P, st, o);
+        T act[E::NK];
+        mlp_forward<T, E::OBS, H, E::NK, LANES>(lds, o, net.activation, lq, act);
+#pragma unroll
+        for (int k = 0; k < E::NK; ++k) {
+            const T eps = noise ? noise[row * E::NK + k] : T(0);
+            act[k] = num<T>::fma(lds[MlpLds<E::OBS, H, E::NK>::STD + k], eps, act[k]);
+        }
+        if (lq == 0) {
+#pragma unroll
+            for (int i = 0; i < E::OBS; ++i) obs[row * E::OBS + i] = o[i];
+#pragma unroll
+            for (int k = 0; k < E::NK; ++k) actions_out[row * E::NK + k] = act[k];
+        }
         StepOut<T> out;
         env_step<T, E, LANES>(P, st, act, out, lq);
         if (lq == 0) {

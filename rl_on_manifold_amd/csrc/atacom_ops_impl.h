@@ -56,6 +56,27 @@ struct Ops {
             hipLaunchKernelGGL((k_rollout<T, E, 1>), dim3(nblk(c.batch, WAVE)), dim3(WAVE), 0, s, make_params<T>(c),
                                n_steps, (T*)f, ip, (const T*)acts, (T*)obs, (T*)nobs, (T*)rew, ab, last);
     }
+    static int rollout_mlp(const atacom_config& c, int lanes, int n_steps, const atacom_mlp& net, void* f, int* ip,
+                           const void* noise, void* obs, void* nobs, void* acts, void* rew, uint8_t* ab, uint8_t* last,
+                           hipStream_t s) {
+        if (E::ID == 0 || net.hidden != 64) return ATACOM_E_UNSUPPORTED;
+        constexpr int H = 64;
+        MlpArgs<T> a;
+        a.W1 = (const T*)net.W1; a.b1 = (const T*)net.b1; a.W2 = (const T*)net.W2; a.b2 = (const T*)net.b2;
+        a.W3 = (const T*)net.W3; a.b3 = (const T*)net.b3; a.obs_shift = (const T*)net.obs_shift;
+        a.obs_scale = (const T*)net.obs_scale; a.std = (const T*)net.std;
+        a.n_in = net.n_in; a.n_out = net.n_out; a.activation = net.activation;
+        const size_t lds_bytes = sizeof(T) * MlpLds<E::OBS, H, E::NK>::TOTAL;
+        if (lanes == 4)
+            hipLaunchKernelGGL((k_rollout_mlp<T, E, 4, H>), dim3(nblk(c.batch * 4, WAVE)), dim3(WAVE), lds_bytes, s,
+                               make_params<T>(c), a, n_steps, (T*)f, ip, (const T*)noise, (T*)obs, (T*)nobs, (T*)acts,
+                               (T*)rew, ab, last);
+        else
+            hipLaunchKernelGGL((k_rollout_mlp<T, E, 1, H>), dim3(nblk(c.batch, WAVE)), dim3(WAVE), lds_bytes, s,
+                               make_params<T>(c), a, n_steps, (T*)f, ip, (const T*)noise, (T*)obs, (T*)nobs, (T*)acts,
+                               (T*)rew, ab, last);
+        return ATACOM_OK;
+    }
     static void reset(const atacom_config& c, void* f, int* ip, const uint8_t* mask, const void* init, void* obs,
                       hipStream_t s) {
         hipLaunchKernelGGL((k_reset<T, E>), dim3(nblk(c.batch, WAVE)), dim3(WAVE), 0, s, make_params<T>(c), (T*)f, ip,
@@ -96,7 +117,7 @@ struct Ops {
     }
     static const EnvOps* table() {
         static const EnvOps ops = {L::COUNT, L::ICOUNT, L::STATE_DIM, L::INIT_DIM, E::OBS, E::NQ, E::NF, E::NG, E::NK,
-                                   sizeof(T), &step, &rollout, &reset, &fill_init, &clear_stats, &stats,
+                                   sizeof(T), &step, &rollout, &rollout_mlp, &reset, &fill_init, &clear_stats, &stats,
                                    &get_state, &set_state, &nullspace, &terms};
         return &ops;
     }

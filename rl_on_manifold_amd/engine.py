@@ -148,6 +148,24 @@ class BatchedAtacomEnv:
         out['action'] = a
         return out
 
+    def rollout_policy(self, policy, n_steps, noise=None, want_next_obs=True):
+        """T env steps with the actor MLP evaluated inside the kernel (row N2): one launch for the whole collection
+        phase.  `policy` is an MlpPolicy (see below); `noise` [T, B, k] standard-normal draws supplied by the caller
+        (None = deterministic mean action).  Returns the same dict as rollout(), 'action' being what the policy drew."""
+        T, B, D, k = int(n_steps), self.batch, self.obs_dim, self.dims['null']
+        net = policy.as_struct(self)
+        nz = None if noise is None else self._as_dev(noise, (T, B, k))
+        out = {'obs': torch.empty((T, B, D), device=self.device, dtype=self.dtype),
+               'next_obs': torch.empty((T, B, D), device=self.device, dtype=self.dtype) if want_next_obs else None,
+               'action': torch.empty((T, B, k), device=self.device, dtype=self.dtype),
+               'reward': torch.empty((T, B), device=self.device, dtype=self.dtype),
+               'absorbing': torch.empty((T, B), device=self.device, dtype=torch.uint8),
+               'last': torch.empty((T, B), device=self.device, dtype=torch.uint8)}
+        _lib.check(self._lib.atacom_rollout_mlp(self._h, T, C.byref(net), _ptr(nz), _ptr(out['obs']),
+                                                 _ptr(out['next_obs']), _ptr(out['action']), _ptr(out['reward']),
+                                                 _ptr(out['absorbing']), _ptr(out['last']), self._stream()))
+        return out
+
     def get_constraints_logs(self, clear=True):
         res = (C.c_double * 3)()
         _lib.check(self._lib.atacom_get_stats(self._h, C.byref(res), int(clear), self._stream()))
@@ -174,6 +192,46 @@ class BatchedAtacomEnv:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+class MlpPolicy:
+    """Weights of a reference-style actor network for BatchedAtacomEnv.rollout_policy.
+
+    `MlpPolicy.from_module(net)` accepts any module with `_h1/_h2/_h3` nn.Linear layers -- exactly the attribute
+    names of the reference's PPONetwork / TRPONetwork / SACActorNetwork (examples/network.py:19-21,50-52,277-279).
+    obs_low / obs_high give the MinMaxPreprocessor normalisation x = (obs - mean) / delta of the finite bounds."""
+
+    def __init__(self, W1, b1, W2, b2, W3, b3, std=None, obs_shift=None, obs_scale=None, activation='relu'):
+        self.tensors = dict(W1=W1, b1=b1, W2=W2, b2=b2, W3=W3, b3=b3, std=std, obs_shift=obs_shift, obs_scale=obs_scale)
+        self.activation = {'relu': 0, 'tanh': 1}[activation]
+        self._keep = None
+
+    @classmethod
+    def from_module(cls, net, std=None, obs_low=None, obs_high=None, activation='relu'):
+        shift = scale = None
+        if obs_low is not None and obs_high is not None:
+            lo = torch.as_tensor(obs_low, dtype=torch.float64)
+            hi = torch.as_tensor(obs_high, dtype=torch.float64)
+            finite = torch.isfinite(lo) & torch.isfinite(hi)
+            shift = torch.where(finite, (hi + lo) / 2, torch.zeros_like(lo))
+            scale = torch.where(finite, 2.0 / (hi - lo).clamp_min(1e-12), torch.ones_like(lo))
+        g = lambda lin: (lin.weight.detach(), lin.bias.detach())      # noqa: E731
+        (W1, b1), (W2, b2), (W3, b3) = g(net._h1), g(net._h2), g(net._h3)
+        return cls(W1, b1, W2, b2, W3, b3, std=std, obs_shift=shift, obs_scale=scale, activation=activation)
+
+    def as_struct(self, env):
+        dev = {k: (None if v is None else torch.as_tensor(v).to(device=env.device, dtype=env.dtype).contiguous())
+               for k, v in self.tensors.items()}
+        self._keep = dev                                   # keep the device copies alive during the launch
+        m = _lib.AtacomMlp()
+        m.struct_size = C.sizeof(_lib.AtacomMlp)
+        m.n_in, m.hidden, m.n_out = dev['W1'].shape[1], dev['W1'].shape[0], dev['W3'].shape[0]
+        if tuple(dev['W2'].shape) != (m.hidden, m.hidden) or dev['W3'].shape[1] != m.hidden:
+            raise ValueError("expected Linear(n_in,h) - Linear(h,h) - Linear(h,n_out)")
+        m.activation = self.activation
+        for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3', 'obs_shift', 'obs_scale', 'std'):
+            setattr(m, k, None if dev[k] is None else dev[k].data_ptr())
+        return m
 
 
 # ---------------------------------------------------------------------- stand-alone primitives

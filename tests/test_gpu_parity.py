@@ -184,6 +184,74 @@ def test_puck_contact_model_against_oracle(name, dt, lanes):
         assert np.median(errs) < 2e-5 and (errs < 2e-3).mean() >= 0.99, (np.median(errs), (errs < 2e-3).mean())
 
 
+def _policy_pair(golden, key, std=0.5, activation='relu'):
+    from rl_on_manifold_amd import MlpPolicy
+    from oracle.policy import MlpPolicy as OraclePolicy
+    g = golden('policy_net')
+    W = [g[key + '._h%d.%s' % (i, w)] for i in (1, 2, 3) for w in ('weight', 'bias')]
+    n_in, n_out = W[0].shape[1], W[4].shape[0]
+    rng = np.random.default_rng(3)
+    shift, scale = rng.uniform(-0.5, 0.5, n_in), rng.uniform(0.5, 2.0, n_in)
+    stdv = np.full(n_out, std)
+    dev = MlpPolicy(*[torch.tensor(w) for w in W], std=torch.tensor(stdv), obs_shift=torch.tensor(shift),
+                    obs_scale=torch.tensor(scale), activation=activation)
+    ora = OraclePolicy(*W, obs_shift=shift, obs_scale=scale, std=stdv, activation=activation)
+    return dev, ora
+
+
+@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('dt', ['f64', 'f32'])
+@pytest.mark.parametrize('name,key', [('iiwa', 'ppo_iiwa'), ('planar', 'sac_planar')])
+def test_policy_rollout_against_oracle(golden, name, key, dt, lanes):
+    """Row N2: actor MLP (the reference's PPONetwork / SACActorNetwork weights) + Gaussian noise + env step fused in
+    one kernel, vs the oracle, one step at a time from identical injected states."""
+    from oracle.policy import rollout as oracle_rollout
+    spec = SPECS[name]()
+    B, T = 256, 12
+    env = _env(name, B, dt, lanes_per_env=lanes)
+    dev, ora = _policy_pair(golden, key, activation='relu' if name == 'iiwa' else 'tanh')
+    nq, ng = spec.dim_q, spec.n_g
+    rng = np.random.default_rng(9)
+    init_q = env.get_state().cpu().numpy().astype(np.float64)[:, :nq] + rng.normal(0, 0.05, (B, nq))
+    o = ob.BatchedAtacomEnv(spec, B, init_q=init_q)
+    errs = []
+    for t in range(T):
+        eps = rng.standard_normal((1, B, spec.n_null))
+        env.set_state(_full_state(env, o))
+        out = env.rollout_policy(dev, 1, noise=torch.tensor(eps))
+        ref = oracle_rollout(o, ora, 1, noise=eps, auto_reset=False)
+        e = np.abs(out['action'][0].cpu().numpy() - ref['action'][0]).max(1)
+        e = np.maximum(e, np.abs(out['next_obs'][0].cpu().numpy() - ref['next_obs'][0]).max(1))
+        e = np.maximum(e, np.abs(out['reward'][0].cpu().numpy() - ref['reward'][0]))
+        assert np.abs(out['obs'][0].cpu().numpy() - ref['obs'][0]).max() < 1e-5
+        errs.append(e)
+    errs = np.array(errs)
+    if dt == 'f64':
+        assert errs.max() < 1e-8, errs.max()
+    else:
+        assert np.median(errs) < 5e-5 and (errs < 3e-3).mean() >= 0.98, (np.median(errs), (errs < 3e-3).mean())
+
+
+def test_policy_rollout_multi_step_consistency(golden):
+    """T-step policy rollout == feeding the actions it drew to the plain rollout kernel; deterministic without noise."""
+    B, T = 192, 10
+    dev, _ = _policy_pair(golden, 'ppo_iiwa')
+    e1 = _env('iiwa', B, 'f32', auto_reset=True, horizon=4)
+    e2 = _env('iiwa', B, 'f32', auto_reset=True, horizon=4)
+    gen = torch.Generator(device=DEV); gen.manual_seed(1)
+    eps = torch.randn((T, B, 5), device=DEV, generator=gen)
+    o1 = e1.rollout_policy(dev, T, noise=eps)
+    o2 = e2.rollout(o1['action'])
+    for k in ('obs', 'next_obs', 'reward'):
+        assert torch.allclose(o1[k], o2[k], rtol=1e-5, atol=1e-6), k
+    assert torch.equal(o1['last'], o2['last']) and o1['last'][3].all() and not o1['last'][2].any()
+    assert torch.allclose(o1['obs'][4], o1['obs'][0])          # auto-reset at the horizon inside the kernel
+    e3 = _env('iiwa', B, 'f32')
+    a = e3.rollout_policy(dev, 2)['action']
+    e3.reset()
+    assert torch.equal(a, e3.rollout_policy(dev, 2)['action'])
+
+
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 def test_circle_reference_trajectories_through_capi(golden, dt):
     """G4: the reference's own CircleEnvAtacom trajectories, replayed step by step through the HIP path."""
