@@ -28,6 +28,9 @@ extern "C" {
 #define ATACOM_ENV_CIRCLE 0 /* atacom/environments/circular_motion/circle_atacom.py:6  CircleEnvAtacom      */
 #define ATACOM_ENV_PLANAR 1 /* atacom/environments/planar_air_hockey/atacom_air_hockey.py:11 (task 'H')     */
 #define ATACOM_ENV_IIWA 2   /* atacom/environments/iiwa_air_hockey/iiwa_hit_atacom.py:10 (env '7H')         */
+/* baseline comparators of the circle experiment (examples/circle_exp.py:85-94), row N3: */
+#define ATACOM_ENV_CIRCLE_EC 3 /* circular_motion/circle_error_correction.py:7 (env 'E'): action = q'' directly + error correction */
+#define ATACOM_ENV_CIRCLE_T 4  /* circular_motion/circle_terminated.py:8 (env 'T'): unconstrained, terminate with -100 at c > tol */
 
 #define ATACOM_F32 0
 #define ATACOM_F64 1
@@ -73,6 +76,7 @@ typedef struct atacom_config {
     double pos_limit[ATACOM_MAX_Q]; /* joint position limits (upper; lower = -upper) */
     double base_xy[2];            /* robot base in the table frame (env_base.py:50) */
     double link[3];               /* planar arm link lengths */
+    double term_tol;              /* ATACOM_ENV_CIRCLE_T: termination tolerance (circle_terminated.py:13, 0.1) */
 } atacom_config;
 
 typedef struct atacom_handle atacom_handle;

@@ -16,7 +16,8 @@ import numpy as np
 
 from . import robots
 from .atacom_scalar import (ENV_CIRCLE, ENV_PLANAR, ENV_IIWA, TABLE_LENGTH, TABLE_WIDTH, GOAL_WIDTH,
-                            MALLET_RADIUS, PUCK_RADIUS, UNIVERSAL_HEIGHT, HIT_RANGE, GOAL_POS, E_MALLET, E_RIM)
+                            MALLET_RADIUS, PUCK_RADIUS, UNIVERSAL_HEIGHT, HIT_RANGE, GOAL_POS, E_MALLET, E_RIM,
+                            MODE_ATACOM, MODE_ERROR_CORRECTION, MODE_TERMINATED)
 
 
 def _diag_batch(x):
@@ -233,6 +234,9 @@ class BatchedAtacomEnv:
         psi = Jdq + sp.K * bst
         c = fun + sp.K * Jdq
         c[:, nf:] += 0.5 * s ** 2
+        if sp.mode == MODE_ERROR_CORRECTION:       # error_correction_wrapper.py:117-130
+            x, _ = bidiag_solve_null(Jc, sp.Kc * c, sp.n_null)
+            return np.concatenate([alpha, np.zeros((B, ng))], -1) - x
         x, N = bidiag_solve_null(Jc, psi + sp.Kc * c, sp.n_null)
         Nr = rref_tol(N, sp.rref_tol)
         return -x + np.einsum('bnk,bk->bn', Nr, alpha)
@@ -246,8 +250,18 @@ class BatchedAtacomEnv:
     def step(self, action):
         sp = self.spec
         nq = sp.dim_q
-        alpha = np.clip(np.asarray(action, dtype=np.float64), -1.0, 1.0) * sp.alpha_max
-        if sp.env_id == ENV_CIRCLE:
+        act = np.clip(np.asarray(action, dtype=np.float64), -1.0, 1.0)
+        alpha = act * (sp.alpha_max if sp.mode == MODE_ATACOM else (sp.acc_max if sp.mode == MODE_ERROR_CORRECTION else 1.0))
+        if sp.env_id == ENV_CIRCLE and sp.mode == MODE_TERMINATED:
+            c_pre = np.stack([np.abs(self.q[:, 0] ** 2 + self.q[:, 1] ** 2 - 1), -self.q[:, 1] - 0.5], -1)
+            dq_pre = np.abs(self.dq) - 1.0
+            self._log(c_pre.max(-1), c_pre.max(-1), dq_pre.max(-1))
+            a = alpha * 10.0
+            self.q = self.q + (self.dq * sp.dt + a * sp.dt ** 2 / 2)
+            self.dq = self.dq + a * sp.dt
+            absorbing = np.maximum(c_pre.max(-1), dq_pre.max(-1)) > sp.term_tol
+            reward = np.where(absorbing, -100.0, np.exp(-np.hypot(1.0 - self.q[:, 0], self.q[:, 1])))
+        elif sp.env_id == ENV_CIRCLE:
             c_pre = np.stack([np.abs(self.q[:, 0] ** 2 + self.q[:, 1] ** 2 - 1), -self.q[:, 1] - 0.5], -1)
             dq_pre = np.abs(self.dq) - 1.0
             self._log(c_pre.max(-1), c_pre.max(-1), dq_pre.max(-1))

@@ -21,6 +21,7 @@ from . import robots
 from .nullspace import pinv_null, rref
 
 ENV_CIRCLE, ENV_PLANAR, ENV_IIWA = 0, 1, 2
+MODE_ATACOM, MODE_ERROR_CORRECTION, MODE_TERMINATED = 0, 1, 2     # wrapper variants
 
 # env_base.py:155-159 (iiwa) -- the MushroomRL planar env uses the same table
 TABLE_LENGTH, TABLE_WIDTH, GOAL_WIDTH = 1.96, 1.02, 0.25
@@ -51,6 +52,8 @@ class EnvSpec:
     bias_mode: str = 'reference'
     rref_tol: float = 0.05   # atacom.py:128
     action_penalty: float = 1e-3
+    mode: int = 0            # MODE_*
+    term_tol: float = 0.1    # circle_terminated.py:13
     base_xy: np.ndarray = field(default_factory=lambda: np.zeros(2))
 
     @property
@@ -62,6 +65,10 @@ class EnvSpec:
         return self.dim_q - self.n_f          # atacom.py:39
 
     @property
+    def action_dim(self):
+        return self.n_null if self.mode == MODE_ATACOM else self.dim_q       # error_correction_wrapper.py:48
+
+    @property
     def alpha_max(self):
         return float(np.max(self.acc_max))    # atacom.py:71
 
@@ -71,6 +78,21 @@ def circle_spec(horizon=500, gamma=0.99, Kc=100.0, dt=0.01):
     return EnvSpec(ENV_CIRCLE, 2, 1, 1, K=np.array([0.1, 2.0]), Kc=np.full(2, float(Kc)),
                    vel_max=np.ones(2), acc_max=np.full(2, 10.0), Kq=np.full(2, 20.0), dt=dt,
                    substeps=1, horizon=horizon, gamma=gamma, obs_dim=4, hold_q=False)
+
+
+def circle_ec_spec(horizon=500, gamma=0.99, Kc=100.0, dt=0.01):
+    """CircleEnvErrorCorrection, circle_error_correction.py:7-21 (same constraints / gains, wrapper 'E')."""
+    sp = circle_spec(horizon, gamma, Kc, dt)
+    sp.mode = MODE_ERROR_CORRECTION
+    return sp
+
+
+def circle_t_spec(horizon=500, gamma=0.99, dt=0.01, tol=0.1):
+    """CircleEnvTerminated, circle_terminated.py:8-29 (no wrapper at all)."""
+    sp = circle_spec(horizon, gamma, 100.0, dt)
+    sp.mode = MODE_TERMINATED
+    sp.term_tol = tol
+    return sp
 
 
 def planar_spec(horizon=120, gamma=0.99, Kc=240.0, dt=1 / 240.0, substeps=4, bias_mode='reference'):
@@ -193,6 +215,19 @@ def tangent_space_accel(spec, q, dq, s, alpha, return_parts=False):
     return mu
 
 
+def error_correction_accel(spec, q, dq, s, alpha):
+    """error_correction_wrapper.py:117-130: mu = [alpha; 0] - Jc^+ (Kc * c); no drift term, no null space."""
+    nq, nf, ng, nc = spec.dim_q, spec.n_f, spec.n_g, spec.n_c
+    fun, J, _ = constraint_terms(spec, q, dq)
+    Jc = np.zeros((nc, nq + ng))
+    Jc[:, :nq] = np.diag(spec.K) @ J
+    Jc[nf:, nq:] = np.diag(s)
+    Jc_inv, _ = pinv_null(Jc)
+    c = fun + spec.K * (J @ dq)
+    c[nf:] += 0.5 * s ** 2
+    return np.concatenate([alpha, np.zeros(ng)]) - Jc_inv @ (spec.Kc * c)
+
+
 def origin_constraints(spec, q):
     """c with origin_constr=True and s = 0, |.| on the equality rows (atacom.py:201-203)."""
     fun, _, _ = constraint_terms(spec, q, np.zeros(spec.dim_q))
@@ -248,14 +283,35 @@ class ScalarAtacomEnv:
     def step(self, action, return_debug=False):
         sp = self.spec
         nq = sp.dim_q
-        alpha = np.clip(np.asarray(action, dtype=np.float64), -1.0, 1.0) * sp.alpha_max   # atacom.py:107-108
+        act = np.clip(np.asarray(action, dtype=np.float64), -1.0, 1.0)
+        if sp.mode == MODE_ATACOM:
+            alpha = act * sp.alpha_max                                                    # atacom.py:107-108
+        elif sp.mode == MODE_ERROR_CORRECTION:
+            alpha = act * sp.acc_max                                                      # error_correction_wrapper.py:106-107
+        else:
+            alpha = act
         dbg = []
-        if sp.env_id == ENV_CIRCLE:
+        if sp.env_id == ENV_CIRCLE and sp.mode == MODE_TERMINATED:
+            # circle_terminated.py:17-29 over circle_base.py:53-67
+            c_pre = np.array([abs(self.q[0] ** 2 + self.q[1] ** 2 - 1), -self.q[1] - 0.5,
+                              abs(self.dq[0]) - 1, abs(self.dq[1]) - 1])
+            self.logs.append(c_pre)
+            a = alpha * 10.0
+            self.q = self.q + (self.dq * sp.dt + a * sp.dt ** 2 / 2)
+            self.dq = self.dq + a * sp.dt
+            reward = float(np.exp(-np.linalg.norm(np.array([1.0, 0.0]) - self.q)))
+            absorbing = bool(np.any(c_pre > sp.term_tol))
+            if absorbing:
+                reward = -100.0
+        elif sp.env_id == ENV_CIRCLE:
             # circle_base.py:53-67 with the ATACOM callback of atacom.py:123-139
             c_pre = np.array([abs(self.q[0] ** 2 + self.q[1] ** 2 - 1), -self.q[1] - 0.5,
                               abs(self.dq[0]) - 1, abs(self.dq[1]) - 1])            # :86-107
             self.logs.append(c_pre)
-            mu = tangent_space_accel(sp, self.q, self.dq, self.s, alpha)
+            if sp.mode == MODE_ERROR_CORRECTION:
+                mu = error_correction_accel(sp, self.q, self.dq, self.s, alpha)
+            else:
+                mu = tangent_space_accel(sp, self.q, self.dq, self.s, alpha)
             self.s = self.s + mu[nq:] * sp.dt                                       # atacom.py:135
             ddq = acc_truncation(sp, self.dq, mu[:nq])                              # :137
             ctrl = ddq / sp.acc_max                                                 # circle_atacom.py:26-27

@@ -18,6 +18,7 @@ Golden sets:
                     sub-steps per step (reproduces the zero-order hold of q, dq -- quirk Q1)
   G6 tables         acc_truncation and _compute_slack_variables
   G7 logs           get_constraints_logs aggregation
+  G9 baselines      CircleEnvErrorCorrection / CircleEnvTerminated trajectories (row N3)
   G8 policy         the reference's actor networks (examples/network.py) forward() on random inputs (row N2)
 """
 import os
@@ -394,6 +395,40 @@ def gen_tables():
     print('tables.npz')
 
 
+def gen_baselines():
+    """G9: the circle experiment's baseline comparators, reference code unchanged:
+    CircleEnvErrorCorrection ('E', circle_error_correction.py) and CircleEnvTerminated ('T', circle_terminated.py)."""
+    from atacom.environments.circular_motion import CircleEnvErrorCorrection, CircleEnvTerminated
+    rng = np.random.default_rng(23)
+    T, n = 300, 6
+    out = {}
+    for tag, cls in (('E', CircleEnvErrorCorrection), ('T', CircleEnvTerminated)):
+        acts = rng.uniform(-1.3, 1.3, (n, T, 2))
+        acts[0] = [1.0, -1.0]
+        rec = {k: [] for k in ('init', 'obs', 'reward', 'absorbing', 's', 'logs')}
+        for i in range(n):
+            env = cls(horizon=T)
+            inner = env.env if tag == 'E' else env
+            if i >= 2:
+                inner.random_init = True
+                np.random.seed(500 + i)
+            st = env.reset().copy()
+            rec['init'].append(st)
+            tr = {k: [] for k in ('obs', 'reward', 'absorbing', 's')}
+            for a in acts[i]:
+                obs, r, ab, _ = env.step(a)
+                tr['obs'].append(np.array(obs).copy()); tr['reward'].append(float(r)); tr['absorbing'].append(bool(ab))
+                tr['s'].append(env.s.copy() if tag == 'E' else np.zeros(1))
+            for k in tr:
+                rec[k].append(np.array(tr[k]))
+            rec['logs'].append(np.array(env.get_constraints_logs()))
+        out[tag + '_actions'] = acts
+        for k, v in rec.items():
+            out[tag + '_' + k] = np.array(v)
+    np.savez_compressed(os.path.join(OUT, 'circle_baselines.npz'), **out)
+    print('circle_baselines.npz', {k: v.shape for k, v in out.items()})
+
+
 def gen_policy():
     """G8: the reference's actor networks (examples/network.py) evaluated by the reference's own forward()."""
     import importlib.util
@@ -423,6 +458,6 @@ def gen_policy():
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    todo = sys.argv[1:] or ['nullspace', 'constraints', 'circle', 'generic', 'tables', 'policy']
+    todo = sys.argv[1:] or ['nullspace', 'constraints', 'circle', 'generic', 'tables', 'policy', 'baselines']
     for name in todo:
         globals()['gen_' + name]()

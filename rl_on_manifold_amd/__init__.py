@@ -13,7 +13,8 @@ def __getattr__(name):
     if name in ('BatchedAtacomEnv', 'nullspace', 'constraint_terms', 'MlpPolicy'):
         from . import engine
         return getattr(engine, name)
-    if name in ('CircleEnvAtacom', 'AirHockeyPlanarAtacom', 'AirHockeyIiwaAtacom'):
+    if name in ('CircleEnvAtacom', 'AirHockeyPlanarAtacom', 'AirHockeyIiwaAtacom', 'CircleEnvErrorCorrection',
+                'CircleEnvTerminated'):
         from . import envs
         return getattr(envs, name)
     if name == 'RolloutCollector':

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # ATACOM_LIB lets kernel-tuning experiments point at an alternative build of the same library
 LIB_PATH = os.environ.get('ATACOM_LIB') or os.path.join(HERE, 'libatacom_hip.so')
 
-ENV_CIRCLE, ENV_PLANAR, ENV_IIWA = 0, 1, 2
+ENV_CIRCLE, ENV_PLANAR, ENV_IIWA, ENV_CIRCLE_EC, ENV_CIRCLE_T = 0, 1, 2, 3, 4
 F32, F64 = 0, 1
 MAX_C, MAX_Q = 12, 6
 
@@ -27,7 +27,7 @@ class AtacomConfig(C.Structure):
                 ('dt', C.c_double), ('rref_tol', C.c_double), ('action_penalty', C.c_double), ('gamma', C.c_double),
                 ('K', C.c_double * MAX_C), ('Kc', C.c_double * MAX_C), ('vel_max', C.c_double * MAX_Q),
                 ('acc_max', C.c_double * MAX_Q), ('Kq', C.c_double * MAX_Q), ('pos_limit', C.c_double * MAX_Q),
-                ('base_xy', C.c_double * 2), ('link', C.c_double * 3)]
+                ('base_xy', C.c_double * 2), ('link', C.c_double * 3), ('term_tol', C.c_double)]
 
 
 class AtacomMlp(C.Structure):

@@ -32,6 +32,8 @@ const atacom::EnvOps* get_ops(int env_id, int dtype) {
         case ATACOM_ENV_CIRCLE: return atacom::ops_circle(dtype);
         case ATACOM_ENV_PLANAR: return atacom::ops_planar(dtype);
         case ATACOM_ENV_IIWA: return atacom::ops_iiwa(dtype);
+        case ATACOM_ENV_CIRCLE_EC: return atacom::ops_circle_ec(dtype);
+        case ATACOM_ENV_CIRCLE_T: return atacom::ops_circle_t(dtype);
         default: return nullptr;
     }
 }
@@ -49,7 +51,7 @@ int pick_lanes(const atacom_config& c) {
 // default initial state rows: [q, dq, puck(6)]
 void default_init_row(int env_id, std::vector<double>& row) {
     const double puck[6] = {-0.4, 0.0, 0.0, 0.0, 0.0, 0.0};   // centre of hit_range, env_hitting.py:11,27
-    if (env_id == ATACOM_ENV_CIRCLE) {
+    if (env_id == ATACOM_ENV_CIRCLE || env_id == ATACOM_ENV_CIRCLE_EC || env_id == ATACOM_ENV_CIRCLE_T) {
         row = {-1.0, 0.0, 0.0, 0.0};                            // circle_base.py:44
     } else if (env_id == ATACOM_ENV_PLANAR) {
         row = {-0.9273, 0.9273, M_PI / 2, 0, 0, 0};             // MushroomRL planar init pose
@@ -100,8 +102,9 @@ int atacom_default_config(int32_t env_id, atacom_config* c) {
     c->rref_tol = 0.05;          // atacom.py:128
     c->gamma = 0.99;
     c->action_penalty = 1e-3;    // env_hitting.py:10
-    if (env_id == ATACOM_ENV_CIRCLE) {
-        // circle_atacom.py:7-18
+    c->term_tol = 0.1;           // circle_terminated.py:13
+    if (env_id == ATACOM_ENV_CIRCLE || env_id == ATACOM_ENV_CIRCLE_EC || env_id == ATACOM_ENV_CIRCLE_T) {
+        // circle_atacom.py:7-18 == circle_error_correction.py:8-21 (same constraints and gains)
         c->substeps = 1; c->horizon = 500; c->dt = 0.01; c->hold_q = 0;
         c->K[0] = 0.1; c->K[1] = 2.0;
         for (int i = 0; i < 2; ++i) { c->Kc[i] = 100.0; c->vel_max[i] = 1.0; c->acc_max[i] = 10.0; c->Kq[i] = 20.0; }

@@ -14,16 +14,25 @@
 
 namespace atacom {
 
+// MODE: 0 = ATACOM wrapper (atacom/atacom.py); 1 = ErrorCorrection baseline "E" (atacom/error_correction_wrapper.py:
+// the action is the joint acceleration itself, only -Jc^+ Kc c is added, q/dq refreshed every sub-step);
+// 2 = Terminated baseline "T" (circle_terminated.py: unconstrained, episode ends with reward -100 when c > tol).
 struct Circle {
-    static constexpr int ID = 0, NQ = 2, NF = 1, NG = 1, NC = 2, NN = 3, NK = 1, OBS = 4;
+    static constexpr int ID = 0, NQ = 2, NF = 1, NG = 1, NC = 2, NN = 3, NK = 1, OBS = 4, MODE = 0;
     static constexpr bool PUCK = false;
 };
+struct CircleEC : Circle {      // CircleEnvErrorCorrection, circle_error_correction.py:7-21
+    static constexpr int NK = 2, MODE = 1;
+};
+struct CircleT : Circle {       // CircleEnvTerminated, circle_terminated.py:8-29
+    static constexpr int NK = 2, MODE = 2;
+};
 struct Planar {
-    static constexpr int ID = 1, NQ = 3, NF = 0, NG = 6, NC = 6, NN = 9, NK = 3, OBS = 12;
+    static constexpr int ID = 1, NQ = 3, NF = 0, NG = 6, NC = 6, NN = 9, NK = 3, OBS = 12, MODE = 0;
     static constexpr bool PUCK = true;
 };
 struct Iiwa {
-    static constexpr int ID = 2, NQ = 6, NF = 1, NG = 11, NC = 12, NN = 17, NK = 5, OBS = 18;
+    static constexpr int ID = 2, NQ = 6, NF = 1, NG = 11, NC = 12, NN = 17, NK = 5, OBS = 18, MODE = 0;
     static constexpr bool PUCK = true;
 };
 
@@ -42,6 +51,7 @@ struct Params {
     T z4_min, z7_min;          // 0.36, 0.25  (iiwa_hit_atacom.py:104-105)
     T puck_r, mallet_r;        // 0.03165, 0.05 (env_base.py:157-158)
     T e_mallet, e_rim;         // restitution of the contact model of this build
+    T term_tol;                // MODE 2: termination tolerance (circle_terminated.py:13)
 };
 
 // ---------------------------------------------------------------------------------------- circle

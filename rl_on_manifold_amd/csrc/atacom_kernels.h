@@ -138,7 +138,10 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
     T anorm2 = T(0);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {                              // atacom.py:107-108
-        alpha[k] = num<T>::min(num<T>::max(act[k], T(-1)), T(1)) * P.alpha_max;
+        // ATACOM scales every null coordinate by max(acc_max); the E baseline scales joint k by acc_max[k]
+        // (error_correction_wrapper.py:106-107); the T baseline hands the raw action to the base env
+        const T sc = (E::MODE == 0) ? P.alpha_max : ((E::MODE == 1) ? P.acc_max[k < NQ ? k : 0] : T(1));
+        alpha[k] = num<T>::min(num<T>::max(act[k], T(-1)), T(1)) * sc;
         anorm2 = num<T>::fma(alpha[k], alpha[k], anorm2);
     }
     if (E::ID == 0) {                                           // circle_base.py:54,86-107 (logged BEFORE the step)
@@ -147,6 +150,24 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
         out.log_avg = out.log_max = num<T>::max(c1, c2);
         out.log_dq = num<T>::max(num<T>::abs(st.dq[0]), num<T>::abs(st.dq[1])) - T(1);
     }
+    if (E::MODE == 2) {
+        // CircleEnvTerminated.step (circle_terminated.py:17-29): plain CircularMotion.step, then absorbing (reward -100)
+        // if any PRE-step constraint value exceeds tol (self.c is set by check_constraint at the top of step)
+        const bool term = num<T>::max(out.log_max, out.log_dq) > P.term_tol;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const T acc = alpha[i < NK ? i : 0] * T(10);                                   // circle_base.py:59-60
+            st.q[i] += num<T>::fma(st.dq[i], P.dt, acc * (P.dt * P.dt) / T(2));
+            st.dq[i] = num<T>::fma(acc, P.dt, st.dq[i]);
+        }
+        const T dxr = T(1) - st.q[0];
+        const T rr = num<T>::exp(-num<T>::sqrt(num<T>::fma(dxr, dxr, st.q[1] * st.q[1])));
+        out.reward = term ? T(-100) : rr;
+        out.absorbing = term;
+        st.t += 1;
+        out.last = out.absorbing || (st.t >= P.horizon);
+        return;
+    }
     T qc[NQ], dqc[NQ];          // what the controller sees (held over the sub-steps when hold_q)
     T m0x = T(0), m0y = T(0);   // mallet position at the start of the env step
     T A[NC][NQ], psi[NC], c0[NC];
@@ -154,7 +175,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
     T Aq[NC][SQ];              // LANES == 4: this lane's columns of [K J | 0]
 #pragma unroll 1
     for (int sub = 0; sub < P.substeps; ++sub) {
-        if (sub == 0 || !P.hold_q) {
+        if (sub == 0 || !P.hold_q || E::MODE == 1) {
 #pragma unroll
             for (int i = 0; i < NQ; ++i) { qc[i] = st.q[i]; dqc[i] = st.dq[i]; }
             T fun[NC], J[NC][NQ], bst[NC];
@@ -195,10 +216,10 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
         for (int r = 0; r < NC; ++r) {
             const T sv = (r >= NF) ? st.s[r >= NF ? r - NF : 0] : T(0);
             const T cs = num<T>::fma(T(0.5) * sv, sv, c0[r]);       // c = fun + K J dq (+ s^2 / 2 on g rows)
-            y[r] = num<T>::fma(P.Kc[r], cs, psi[r]);
+            y[r] = (E::MODE == 1) ? P.Kc[r] * cs : num<T>::fma(P.Kc[r], cs, psi[r]);   // E: no drift term (:127)
         }
-        if (LANES == 1) {
-            T a[NC][NN], x[NN], nb[NN][NK], nmu[NN];
+        if (LANES == 1 || E::MODE != 0) {
+            T a[NC][NN], x[NN], nb[NN][NN - NC], nmu[NN];
 #pragma unroll
             for (int r = 0; r < NC; ++r) {
 #pragma unroll
@@ -207,12 +228,25 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 for (int g = 0; g < NG; ++g) a[r][NQ + g] = (r == NF + g) ? st.s[g] : T(0);
             }
             bidiag_solve_null<T, NC, NN>(a, y, x, nb);              // atacom.py:127 (pinv_null)
-            rref_apply<T, NN, NK>(nb, alpha, P.rref_tol, nmu);      // atacom.py:128,131
+            if (E::MODE == 1) {
+                // error_correction_wrapper.py:127-130: [alpha; 0] - Jc^+ (Kc c), the null basis is not used
 #pragma unroll
-            for (int n = 0; n < NN; ++n) mu[n] = nmu[n] - x[n];     // atacom.py:130-133
+                for (int n = 0; n < NN; ++n) mu[n] = ((n < NQ) ? alpha[n < NK ? n : 0] : T(0)) - x[n];
+            } else {
+                T alpha0[NN - NC];
+#pragma unroll
+                for (int k = 0; k < NN - NC; ++k) alpha0[k] = alpha[k < NK ? k : 0];
+                rref_apply<T, NN, NN - NC>(nb, alpha0, P.rref_tol, nmu);      // atacom.py:128,131
+#pragma unroll
+                for (int n = 0; n < NN; ++n) mu[n] = nmu[n] - x[n];           // atacom.py:130-133
+            }
         } else {
             constexpr int S = (NN + 3) / 4;
-            T a[NC][S], x[S], nb[S][NK], nmu[S];
+            constexpr int ND = NN - NC;
+            T a[NC][S], x[S], nb[S][ND], nmu[S];
+            T alphaq[ND];
+#pragma unroll
+            for (int k = 0; k < ND; ++k) alphaq[k] = alpha[k < NK ? k : 0];
             // this lane's columns: the K J block was split once per step (Aq), the slack diagonal entry of
             // row r sits in column NQ + r - NF, i.e. slot (NQ+r-NF)/4 of lane (NQ+r-NF)%4
 #pragma unroll
@@ -225,7 +259,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 }
             }
             bidiag_solve_null_quad<T, NC, NN>(a, y, x, nb, lq);
-            rref_apply_quad<T, NN, NK>(nb, alpha, P.rref_tol, nmu, lq);
+            rref_apply_quad<T, NN, ND>(nb, alphaq, P.rref_tol, nmu, lq);
 #pragma unroll
             for (int n = 0; n < NN; ++n) {                          // gather mu back to every lane of the quad
                 const T o = nmu[n / 4] - x[n / 4];
@@ -623,7 +657,7 @@ template <typename T, typename E>
 __global__ void __launch_bounds__(WAVE) k_nullspace(int n, const T* __restrict__ Jc, const T* __restrict__ rhs,
                                                     T tol, T* __restrict__ xo, T* __restrict__ nullo,
                                                     T* __restrict__ rrefo) {
-    constexpr int NC = E::NC, NN = E::NN, NK = E::NK;
+    constexpr int NC = E::NC, NN = E::NN, NK = E::NN - E::NC;     // NK here = null-space dimension
     const int b = blockIdx.x * WAVE + threadIdx.x;
     if (b >= n) return;
     T a[NC][NN], y[NC], x[NN], nb[NN][NK];
@@ -667,7 +701,7 @@ template <typename T, typename E>
 __global__ void __launch_bounds__(WAVE) k_nullspace_quad(int n, const T* __restrict__ Jc, const T* __restrict__ rhs,
                                                          T tol, T* __restrict__ xo, T* __restrict__ nullo,
                                                          T* __restrict__ rrefo) {
-    constexpr int NC = E::NC, NN = E::NN, NK = E::NK, S = (NN + 3) / 4;
+    constexpr int NC = E::NC, NN = E::NN, NK = E::NN - E::NC, S = (NN + 3) / 4;
     const int gt = blockIdx.x * WAVE + threadIdx.x;
     const int b = gt >> 2, lq = gt & 3;
     if (b >= n) return;

@@ -33,6 +33,8 @@ struct EnvOps {
 };
 
 const EnvOps* ops_circle(int dtype);
+const EnvOps* ops_circle_ec(int dtype);
+const EnvOps* ops_circle_t(int dtype);
 const EnvOps* ops_planar(int dtype);
 const EnvOps* ops_iiwa(int dtype);
 

@@ -17,7 +17,7 @@ static Params<T> make_params(const atacom_config& c) {
         P.vel_max[i] = (T)c.vel_max[i]; P.acc_max[i] = (T)c.acc_max[i]; P.Kq[i] = (T)c.Kq[i];
         P.pos_limit[i] = (T)c.pos_limit[i];
     }
-    const int nq = c.env_id == ATACOM_ENV_CIRCLE ? 2 : (c.env_id == ATACOM_ENV_PLANAR ? 3 : 6);
+    const int nq = c.env_id == ATACOM_ENV_PLANAR ? 3 : (c.env_id == ATACOM_ENV_IIWA ? 6 : 2);
     for (int i = 1; i < nq; ++i) amax = c.acc_max[i] > amax ? c.acc_max[i] : amax;
     P.alpha_max = (T)amax;                       // atacom.py:71
     P.base_x = (T)c.base_xy[0]; P.base_y = (T)c.base_xy[1];
@@ -29,6 +29,7 @@ static Params<T> make_params(const atacom_config& c) {
     P.goal_x = (T)0.98; P.goal_y = (T)0.0; P.goal_w = (T)0.25;
     P.ee_height = (T)0.1505; P.z4_min = (T)0.36; P.z7_min = (T)0.25;
     P.puck_r = (T)0.03165; P.mallet_r = (T)mallet_r; P.e_mallet = (T)0.8; P.e_rim = (T)0.8;
+    P.term_tol = (T)c.term_tol;
     return P;
 }
 

@@ -12,7 +12,8 @@ from . import _lib
 from .spaces import Box, MDPInfo
 
 _ENV_IDS = {'circle': _lib.ENV_CIRCLE, 'A': _lib.ENV_CIRCLE, 'planar': _lib.ENV_PLANAR, 'H': _lib.ENV_PLANAR,
-            'iiwa': _lib.ENV_IIWA, '7H': _lib.ENV_IIWA}
+            'iiwa': _lib.ENV_IIWA, '7H': _lib.ENV_IIWA, 'circle_ec': _lib.ENV_CIRCLE_EC, 'E': _lib.ENV_CIRCLE_EC,
+            'circle_t': _lib.ENV_CIRCLE_T, 'T': _lib.ENV_CIRCLE_T}
 
 
 def _ptr(t):
@@ -32,7 +33,7 @@ class BatchedAtacomEnv:
 
     def __init__(self, env, batch, device='cuda:0', dtype=torch.float32, horizon=None, gamma=None, Kc=None,
                  time_step=None, n_intermediate_steps=None, action_penalty=None, auto_reset=False,
-                 hold_q=None, bias_mode='reference', rref_tol=None, lanes_per_env=0):
+                 hold_q=None, bias_mode='reference', rref_tol=None, lanes_per_env=0, term_tol=None):
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.AtacomError("BatchedAtacomEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -62,9 +63,13 @@ class BatchedAtacomEnv:
         cfg.bias_mode = {'reference': 0, 'exact': 1}[bias_mode]
         cfg.auto_reset = int(bool(auto_reset))
         cfg.lanes_per_env = int(lanes_per_env)      # 0 auto, 1 lane-per-env, 4 quad-per-env kernels
+        if term_tol is not None:
+            cfg.term_tol = float(term_tol)
         d = _lib.get_dims(self.env_id)
         self.dims = {'q': d.dim_q, 'f': d.n_f, 'g': d.n_g, 'null': d.n_null, 'c': d.n_f + d.n_g}   # atacom.py:25-40
         self.obs_dim, self.state_dim, self.init_state_dim = d.obs_dim, d.state_dim, d.init_state_dim
+        # get_dims reports the ACTION dimension in n_null: dim_q - n_f for ATACOM (atacom.py:39,51), dim_q for the
+        # 'E' / 'T' baselines (error_correction_wrapper.py:48, circle_base.py:24)
         if Kc is not None:
             kc = np.broadcast_to(np.asarray(Kc, dtype=np.float64), (self.dims['c'],))
             for i in range(self.dims['c']):

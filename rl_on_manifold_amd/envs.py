@@ -82,6 +82,28 @@ class CircleEnvAtacom(_Facade):
         return self.state
 
 
+class CircleEnvErrorCorrection(CircleEnvAtacom):
+    """Baseline 'E' (circle_error_correction.py:7-21): the action is the 2-d acceleration, only the error-correction
+    term -Jc^+ Kc c is added.  Same constructor as the reference."""
+    _env_name = 'circle_ec'
+
+    def __init__(self, horizon=500, gamma=0.99, random_init=False, Kc=100., time_step=0.01, device='cuda:0',
+                 dtype=torch.float32):
+        super().__init__(horizon=horizon, gamma=gamma, random_init=random_init, Kc=Kc, time_step=time_step,
+                         device=device, dtype=dtype)
+
+
+class CircleEnvTerminated(CircleEnvAtacom):
+    """Baseline 'T' (circle_terminated.py:8-29): unconstrained 2-d acceleration control, the episode ends with reward
+    -100 as soon as a constraint value exceeds `tol`.  Same constructor as the reference."""
+    _env_name = 'circle_t'
+
+    def __init__(self, time_step=0.01, horizon=500, gamma=0.99, random_init=False, tol=0.1, device='cuda:0',
+                 dtype=torch.float32):
+        self.random_init = random_init
+        self._make(horizon=horizon, gamma=gamma, time_step=time_step, term_tol=tol, device=device, dtype=dtype)
+
+
 class _AirHockeyFacade(_Facade):
     def _init_common(self, task, gamma, horizon, timestep, n_intermediate_steps, env_noise, obs_noise, obs_delay,
                      Kc, random_init, action_penalty, device, dtype):

@@ -184,6 +184,34 @@ def test_puck_contact_model_against_oracle(name, dt, lanes):
         assert np.median(errs) < 2e-5 and (errs < 2e-3).mean() >= 0.99, (np.median(errs), (errs < 2e-3).mean())
 
 
+@pytest.mark.parametrize('dt', ['f64', 'f32'])
+@pytest.mark.parametrize('tag', ['E', 'T'])
+def test_baseline_wrappers_reference_trajectories_through_capi(golden, tag, dt):
+    """Row N3, golden set G9: the reference's CircleEnvErrorCorrection / CircleEnvTerminated, replayed through HIP."""
+    g = golden('circle_baselines')
+    acts, obs, rew, absb, s, init = (g[tag + '_' + k] for k in ('actions', 'obs', 'reward', 'absorbing', 's', 'init'))
+    n, T = acts.shape[:2]
+    env = _env('circle_ec' if tag == 'E' else 'circle_t', n, dt, horizon=300)
+    assert env.dims['null'] == 2 and env.info.action_space.shape == (2,)
+    spec = osc.circle_ec_spec()
+    full = np.zeros((n, env.state_dim))
+    worst = 0.0
+    for t in range(T):
+        prev = init if t == 0 else obs[:, t - 1]
+        s_prev = (np.array([osc.slack_init(spec, p[:2], p[2:]) for p in init]) if t == 0 else s[:, t - 1]) if tag == 'E' else 0.0
+        full[:, :4], full[:, 4:5], full[:, -1] = prev, s_prev, t
+        env.set_state(full)
+        o, r, ab, _ = env.step(acts[:, t])
+        worst = max(worst, np.abs(o.cpu().numpy() - obs[:, t]).max(), np.abs(r.cpu().numpy() - rew[:, t]).max())
+        assert (ab.cpu().numpy() == absb[:, t]).all()
+    assert worst < (1e-9 if dt == 'f64' else 5e-4), worst
+    from rl_on_manifold_amd import CircleEnvErrorCorrection, CircleEnvTerminated
+    m = (CircleEnvErrorCorrection if tag == 'E' else CircleEnvTerminated)(horizon=300)
+    st = m.reset()
+    o, r, ab, info = m.step(acts[0, 0])
+    assert np.allclose(st, [-1, 0, 0, 0]) and np.allclose(o, obs[0, 0], atol=1e-5) and isinstance(ab, bool)
+
+
 def _policy_pair(golden, key, std=0.5, activation='relu'):
     from rl_on_manifold_amd import MlpPolicy
     from oracle.policy import MlpPolicy as OraclePolicy
