@@ -40,12 +40,15 @@ const atacom::EnvOps* get_ops(int env_id, int dtype) {
 
 constexpr int kStatBlocks = 256;
 
-// kernel mapping policy for lanes_per_env = 0 (measured on MI355X, profiles/): the quad-cooperative
-// kernels win whenever the 12x17 problem is solved (iiwa); the small environments are launch-bound.
+// kernel mapping policy for lanes_per_env = 0, from measurements on MI355X (profiles/r01_lanes_vs_batch.md):
+// the quad mapping has ~0.56x the instructions per wave but 4x the waves, so it wins while the batch cannot
+// fill the 1024 SIMDs with one-env-per-lane waves, and loses once it can.
 int pick_lanes(const atacom_config& c) {
     if (c.lanes_per_env == 1 || c.lanes_per_env == 4) return c.lanes_per_env;
     if (c.dtype == ATACOM_F64) return 1;
-    return c.env_id == ATACOM_ENV_IIWA ? 4 : 1;
+    if (c.env_id == ATACOM_ENV_IIWA) return c.batch <= 16384 ? 4 : 1;      // 58 vs 79 us @8192; 113 vs 102 us @24576
+    if (c.env_id == ATACOM_ENV_PLANAR) return (c.batch >= 2048 && c.batch <= 40960) ? 4 : 1;   // 20.5 vs 25 us @8192
+    return 1;                                                              // circle: launch-bound either way
 }
 
 // default initial state rows: [q, dq, puck(6)]

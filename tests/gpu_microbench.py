@@ -6,7 +6,7 @@ from rl_on_manifold_amd import BatchedAtacomEnv
 dev = 'cuda:0'
 tag = os.environ.get('ATACOM_LIB', 'default')
 for name in sys.argv[1:] or ['iiwa']:
-    for B in (8192,):
+    for B in [int(x) for x in os.environ.get("MB_BATCHES", "8192").split(",")]:
       for lanes in (1, 4):
         env = BatchedAtacomEnv(name, B, device=dev, dtype=torch.float32, auto_reset=True, lanes_per_env=lanes)
         k = env.dims['null']
