@@ -108,9 +108,13 @@ __device__ __forceinline__ void bidiag_solve_null_quad(T (&a)[M][(N + 3) / 4], T
                 for (int s = si; s < S; ++s) a[r][s] = num<T>::fma(-w, a[i][s], a[r][s]);
             }
             // ---- left reflector H(i) from column i (slot si of lane li), rows i+1..M-1
-            T sup = T(0);
+            T sup0 = T(0), sup1 = T(0);                  // two accumulators: the chain is on the critical path
 #pragma unroll
-            for (int r = i + 2; r < M; ++r) sup = num<T>::fma(a[r][si], a[r][si], sup);
+            for (int r = i + 2; r < M; ++r) {
+                if ((r - i) & 1) sup1 = num<T>::fma(a[r][si], a[r][si], sup1);
+                else sup0 = num<T>::fma(a[r][si], a[r][si], sup0);
+            }
+            const T sup = sup0 + sup1;
             T su, alq;
             T u[M];
             if (li == 0) { su = qbcast<0>(sup); alq = qbcast<0>(a[i + 1][si]); }
@@ -128,10 +132,13 @@ __device__ __forceinline__ void bidiag_solve_null_quad(T (&a)[M][(N + 3) / 4], T
             }
 #pragma unroll
             for (int s = si; s < S; ++s) {
-                T w = a[i + 1][s];
+                T w = a[i + 1][s], w1 = T(0);
 #pragma unroll
-                for (int r = i + 2; r < M; ++r) w = num<T>::fma(u[r], a[r][s], w);
-                w *= tq;
+                for (int r = i + 2; r < M; ++r) {
+                    if ((r - i) & 1) w1 = num<T>::fma(u[r], a[r][s], w1);
+                    else w = num<T>::fma(u[r], a[r][s], w);
+                }
+                w = (w + w1) * tq;
                 if (s == si) w = (lq > li) ? w : T(0);          // columns <= i are not touched
                 a[i + 1][s] -= w;
 #pragma unroll
