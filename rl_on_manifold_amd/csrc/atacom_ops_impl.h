@@ -38,44 +38,67 @@ static inline int nblk(int n, int per) { return (n + per - 1) / per; }
 template <typename T, typename E>
 struct Ops {
     using L = Planes<E>;
+    // kernel variants: LANES in {1, 4} x HOLD in {true, false}
+    template <int LANES, bool HOLD>
+    static void launch_step(const atacom_config& c, void* f, int* ip, const void* act, void* obs, void* rew,
+                            uint8_t* ab, uint8_t* last, hipStream_t s) {
+        hipLaunchKernelGGL((k_step<T, E, LANES, HOLD>), dim3(nblk(c.batch * LANES, WAVE)), dim3(WAVE), 0, s,
+                           make_params<T>(c), (T*)f, ip, (const T*)act, (T*)obs, (T*)rew, ab, last);
+    }
     static void step(const atacom_config& c, int lanes, void* f, int* ip, const void* act, void* obs, void* rew,
                      uint8_t* ab, uint8_t* last, hipStream_t s) {
-        if (lanes == 4)
-            hipLaunchKernelGGL((k_step<T, E, 4>), dim3(nblk(c.batch * 4, WAVE)), dim3(WAVE), 0, s, make_params<T>(c),
-                               (T*)f, ip, (const T*)act, (T*)obs, (T*)rew, ab, last);
-        else
-            hipLaunchKernelGGL((k_step<T, E, 1>), dim3(nblk(c.batch, WAVE)), dim3(WAVE), 0, s, make_params<T>(c),
-                               (T*)f, ip, (const T*)act, (T*)obs, (T*)rew, ab, last);
+        if (lanes == 4) {
+            if (c.hold_q) launch_step<4, true>(c, f, ip, act, obs, rew, ab, last, s);
+            else launch_step<4, false>(c, f, ip, act, obs, rew, ab, last, s);
+        } else {
+            if (c.hold_q) launch_step<1, true>(c, f, ip, act, obs, rew, ab, last, s);
+            else launch_step<1, false>(c, f, ip, act, obs, rew, ab, last, s);
+        }
+    }
+    template <int LANES, bool HOLD>
+    static void launch_rollout(const atacom_config& c, int n_steps, void* f, int* ip, const void* acts, void* obs,
+                               void* nobs, void* rew, uint8_t* ab, uint8_t* last, hipStream_t s) {
+        hipLaunchKernelGGL((k_rollout<T, E, LANES, HOLD>), dim3(nblk(c.batch * LANES, WAVE)), dim3(WAVE), 0, s,
+                           make_params<T>(c), n_steps, (T*)f, ip, (const T*)acts, (T*)obs, (T*)nobs, (T*)rew, ab, last);
     }
     static void rollout(const atacom_config& c, int lanes, int n_steps, void* f, int* ip, const void* acts, void* obs,
                         void* nobs, void* rew, uint8_t* ab, uint8_t* last, hipStream_t s) {
-        if (lanes == 4)
-            hipLaunchKernelGGL((k_rollout<T, E, 4>), dim3(nblk(c.batch * 4, WAVE)), dim3(WAVE), 0, s,
-                               make_params<T>(c), n_steps, (T*)f, ip, (const T*)acts, (T*)obs, (T*)nobs, (T*)rew, ab,
-                               last);
-        else
-            hipLaunchKernelGGL((k_rollout<T, E, 1>), dim3(nblk(c.batch, WAVE)), dim3(WAVE), 0, s, make_params<T>(c),
-                               n_steps, (T*)f, ip, (const T*)acts, (T*)obs, (T*)nobs, (T*)rew, ab, last);
+        if (lanes == 4) {
+            if (c.hold_q) launch_rollout<4, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
+            else launch_rollout<4, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
+        } else {
+            if (c.hold_q) launch_rollout<1, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
+            else launch_rollout<1, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
+        }
+    }
+    template <int LANES, bool HOLD>
+    static void launch_mlp(const atacom_config& c, int n_steps, const MlpArgs<T>& a, void* f, int* ip,
+                           const void* noise, void* obs, void* nobs, void* acts, void* rew, uint8_t* ab,
+                           uint8_t* last, hipStream_t s) {
+        constexpr int H = 64;
+        const size_t lds_bytes = sizeof(T) * MlpLds<E::OBS, H, E::NK>::TOTAL;
+        hipLaunchKernelGGL((k_rollout_mlp<T, E, LANES, HOLD, H>), dim3(nblk(c.batch * LANES, WAVE)), dim3(WAVE),
+                           lds_bytes, s, make_params<T>(c), a, n_steps, (T*)f, ip, (const T*)noise, (T*)obs, (T*)nobs,
+                           (T*)acts, (T*)rew, ab, last);
     }
     static int rollout_mlp(const atacom_config& c, int lanes, int n_steps, const atacom_mlp& net, void* f, int* ip,
                            const void* noise, void* obs, void* nobs, void* acts, void* rew, uint8_t* ab, uint8_t* last,
                            hipStream_t s) {
         if (E::ID == 0 || net.hidden != 64) return ATACOM_E_UNSUPPORTED;
-        constexpr int H = 64;
         MlpArgs<T> a;
         a.W1 = (const T*)net.W1; a.b1 = (const T*)net.b1; a.W2 = (const T*)net.W2; a.b2 = (const T*)net.b2;
         a.W3 = (const T*)net.W3; a.b3 = (const T*)net.b3; a.obs_shift = (const T*)net.obs_shift;
         a.obs_scale = (const T*)net.obs_scale; a.std = (const T*)net.std;
         a.n_in = net.n_in; a.n_out = net.n_out; a.activation = net.activation;
-        const size_t lds_bytes = sizeof(T) * MlpLds<E::OBS, H, E::NK>::TOTAL;
-        if (lanes == 4)
-            hipLaunchKernelGGL((k_rollout_mlp<T, E, 4, H>), dim3(nblk(c.batch * 4, WAVE)), dim3(WAVE), lds_bytes, s,
-                               make_params<T>(c), a, n_steps, (T*)f, ip, (const T*)noise, (T*)obs, (T*)nobs, (T*)acts,
-                               (T*)rew, ab, last);
-        else
-            hipLaunchKernelGGL((k_rollout_mlp<T, E, 1, H>), dim3(nblk(c.batch, WAVE)), dim3(WAVE), lds_bytes, s,
-                               make_params<T>(c), a, n_steps, (T*)f, ip, (const T*)noise, (T*)obs, (T*)nobs, (T*)acts,
-                               (T*)rew, ab, last);
+        if constexpr (E::ID != 0) {
+            if (lanes == 4) {
+                if (c.hold_q) launch_mlp<4, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
+                else launch_mlp<4, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
+            } else {
+                if (c.hold_q) launch_mlp<1, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
+                else launch_mlp<1, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
+            }
+        }
         return ATACOM_OK;
     }
     static void reset(const atacom_config& c, void* f, int* ip, const uint8_t* mask, const void* init, void* obs,

@@ -136,6 +136,34 @@ def test_env_step_teacher_forced_against_oracle(name, dt, lanes):
 
 
 @pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('name', ['planar', 'iiwa'])
+def test_refresh_and_exact_bias_variants_against_oracle(name, lanes):
+    """The two documented deviations-by-flag from the reference's quirks: hold_q = 0 (q, dq refreshed every sub-step
+    instead of the zero-order hold, quirk Q1) and bias_mode = exact (true dJ/dt dq instead of w x v, quirk Q2)."""
+    spec = SPECS[name](bias_mode='exact')
+    spec.hold_q = False
+    B, T = 384, 16
+    env = _env(name, B, 'f64', lanes_per_env=lanes, hold_q=False, bias_mode='exact')
+    nq, ng = spec.dim_q, spec.n_g
+    rng = np.random.default_rng(13)
+    init_q = env.get_state().cpu().numpy()[:, :nq] + rng.normal(0, 0.05, (B, nq))
+    o = ob.BatchedAtacomEnv(spec, B, init_q=init_q, init_puck=np.array([0.8, 0.4, 0, 0, 0, 0.0]))
+    worst = 0.0
+    for t in range(T):
+        a = rng.uniform(-1.2, 1.2, (B, spec.n_null))
+        env.set_state(_full_state(env, o))
+        obs, r, ab, _ = env.step(a)
+        oo, orr, oab, _ = o.step(a)
+        worst = max(worst, np.abs(obs.cpu().numpy() - oo).max(), np.abs(r.cpu().numpy() - orr).max())
+    assert worst < 1e-8, worst
+    # and the variants really differ from the defaults
+    env_d = _env(name, B, 'f64', lanes_per_env=lanes)
+    env_d.set_state(_full_state(env_d, o)); env.set_state(_full_state(env, o))
+    a = rng.uniform(-1.0, 1.0, (B, spec.n_null))
+    assert (env_d.step(a)[0] - env.step(a)[0]).abs().max() > 1e-6
+
+
+@pytest.mark.parametrize('lanes', [1, 4])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 @pytest.mark.parametrize('name', ['planar', 'iiwa'])
 def test_puck_contact_model_against_oracle(name, dt, lanes):
