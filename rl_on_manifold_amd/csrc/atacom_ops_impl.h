@@ -42,7 +42,7 @@ struct Ops {
     template <int LANES, bool HOLD>
     static void launch_step(const atacom_config& c, void* f, int* ip, const void* act, void* obs, void* rew,
                             uint8_t* ab, uint8_t* last, hipStream_t s) {
-        hipLaunchKernelGGL((k_step<T, E, LANES, HOLD>), dim3(nblk(c.batch * LANES, WAVE)), dim3(WAVE), 0, s,
+        hipLaunchKernelGGL((k_step<T, E, LANES, HOLD>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)), dim3(BLOCK<LANES>), 0, s,
                            make_params<T>(c), (T*)f, ip, (const T*)act, (T*)obs, (T*)rew, ab, last);
     }
     static void step(const atacom_config& c, int lanes, void* f, int* ip, const void* act, void* obs, void* rew,
@@ -58,7 +58,7 @@ struct Ops {
     template <int LANES, bool HOLD>
     static void launch_rollout(const atacom_config& c, int n_steps, void* f, int* ip, const void* acts, void* obs,
                                void* nobs, void* rew, uint8_t* ab, uint8_t* last, hipStream_t s) {
-        hipLaunchKernelGGL((k_rollout<T, E, LANES, HOLD>), dim3(nblk(c.batch * LANES, WAVE)), dim3(WAVE), 0, s,
+        hipLaunchKernelGGL((k_rollout<T, E, LANES, HOLD>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)), dim3(BLOCK<LANES>), 0, s,
                            make_params<T>(c), n_steps, (T*)f, ip, (const T*)acts, (T*)obs, (T*)nobs, (T*)rew, ab, last);
     }
     static void rollout(const atacom_config& c, int lanes, int n_steps, void* f, int* ip, const void* acts, void* obs,
@@ -77,7 +77,8 @@ struct Ops {
                            uint8_t* last, hipStream_t s) {
         constexpr int H = 64;
         const size_t lds_bytes = sizeof(T) * MlpLds<E::OBS, H, E::NK>::TOTAL;
-        hipLaunchKernelGGL((k_rollout_mlp<T, E, LANES, HOLD, H>), dim3(nblk(c.batch * LANES, WAVE)), dim3(WAVE),
+        hipLaunchKernelGGL((k_rollout_mlp<T, E, LANES, HOLD, H>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)),
+                           dim3(BLOCK<LANES>),
                            lds_bytes, s, make_params<T>(c), a, n_steps, (T*)f, ip, (const T*)noise, (T*)obs, (T*)nobs,
                            (T*)acts, (T*)rew, ab, last);
     }
