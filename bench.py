@@ -75,13 +75,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # BENCH_DIST_BACKEND=gloo lets the multi-rank control flow be exercised on a box with fewer GPUs than ranks
+    # (ranks then share devices); the driver's runs use the default, nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
+    dev = torch.device('cuda', local_rank % max(torch.cuda.device_count(), 1))
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world)
-    dev = torch.device('cuda', local_rank)
-    torch.cuda.set_device(dev)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = dev if backend == 'nccl' else torch.device('cpu')
 
     B, K, W = args.batch, args.steps, args.warmup
     env = BatchedAtacomEnv(args.env, B, device=dev, dtype=torch.float32, auto_reset=True)
@@ -134,10 +137,10 @@ def main():
     kern_ms_iso = float(np.median([a.elapsed_time(b) for a, b in ev]))
     c_avg, c_max, c_dq_max = env.get_constraints_logs()
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cm = torch.tensor([c_max, c_dq_max], device=dev, dtype=torch.float64)
+        cm = torch.tensor([c_max, c_dq_max], device=red_dev, dtype=torch.float64)
         dist.all_reduce(cm, op=dist.ReduceOp.MAX)
         c_max, c_dq_max = float(cm[0].item()), float(cm[1].item())
 
