@@ -83,6 +83,7 @@ __device__ __forceinline__ void bidiag_solve_null(T (&a)[M][N], T (&y)[M], T (&x
     T d[M], e[M], taup[M];
 #pragma unroll
     for (int i = 0; i < M; ++i) {
+        __builtin_amdgcn_sched_barrier(0);     // do not overlap reflector steps: keeps the live set near M*N
         // ---- right reflector G(i): annihilate a[i][i+1..N)
         T ss = T(0);
 #pragma unroll
@@ -148,6 +149,7 @@ __device__ __forceinline__ void bidiag_solve_null(T (&a)[M][N], T (&y)[M], T (&x
     // ---- [x | nb] <- G(1) ... G(M) [x | nb]
 #pragma unroll
     for (int i = M - 1; i >= 0; --i) {
+        __builtin_amdgcn_sched_barrier(0);
         {
             T w = x[i];
 #pragma unroll
