@@ -422,6 +422,11 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     if (b >= B) return;
     EnvState<T, E> st;
     load_state<T, E>(f, ip, B, b, st);
+    // the statistics accumulators are read up front with the rest of the state: a read-modify-write at the end
+    // would make the store tail wait on loads queued behind ~60 stores (vmcnt counts both on gfx9-class hardware)
+    const T ssum0 = f[L::SSUM * (size_t)B + b], scmax0 = f[L::SCMAX * (size_t)B + b];
+    const T sdq0 = f[L::SDQMAX * (size_t)B + b];
+    const int cnt0 = ip[L::I_CNT * (size_t)B + b];
     T act[E::NK];
 #pragma unroll
     for (int k = 0; k < E::NK; ++k) act[k] = action[(size_t)b * E::NK + k];
@@ -433,10 +438,10 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     reward[b] = out.reward;
     absorbing[b] = out.absorbing ? 1 : 0;
     if (last) last[b] = out.last ? 1 : 0;
-    f[L::SSUM * (size_t)B + b] += out.log_avg;
-    f[L::SCMAX * (size_t)B + b] = num<T>::max(f[L::SCMAX * (size_t)B + b], out.log_max);
-    f[L::SDQMAX * (size_t)B + b] = num<T>::max(f[L::SDQMAX * (size_t)B + b], out.log_dq);
-    ip[L::I_CNT * (size_t)B + b] += 1;
+    f[L::SSUM * (size_t)B + b] = ssum0 + out.log_avg;
+    f[L::SCMAX * (size_t)B + b] = num<T>::max(scmax0, out.log_max);
+    f[L::SDQMAX * (size_t)B + b] = num<T>::max(sdq0, out.log_dq);
+    ip[L::I_CNT * (size_t)B + b] = cnt0 + 1;
     if (P.auto_reset && out.last) load_init<T, E>(f, B, b, st);
     store_state<T, E>(f, ip, B, b, st);
 }
