@@ -77,6 +77,10 @@ typedef struct atacom_config {
     double base_xy[2];            /* robot base in the table frame (env_base.py:50) */
     double link[3];               /* planar arm link lengths */
     double term_tol;              /* ATACOM_ENV_CIRCLE_T: termination tolerance (circle_terminated.py:13, 0.1) */
+    int32_t random_init;          /* 1 = every reset (explicit without a state, or auto) re-draws the random part of the
+                                     reference's reset on the device: circle point + tangential velocity
+                                     (circle_base.py:36-42), puck position in hit_range (env_hitting.py:24-25) */
+    int32_t seed;                 /* seed of the counter-based generator hash(seed, env, episode, draw) */
 } atacom_config;
 
 typedef struct atacom_handle atacom_handle;

@@ -166,10 +166,25 @@ def rref_tol(N, tol):
     return np.swapaxes(V, 1, 2)
 
 
+def device_uniform(seed, env, episode, draw):
+    """The engine's counter-based generator (atacom_kernels.h: device_uniform), restated with numpy uint32 arithmetic."""
+    def h(x):
+        x = np.asarray(x, dtype=np.uint64) & 0xffffffff
+        x ^= x >> 16; x = (x * 0x7feb352d) & 0xffffffff
+        x ^= x >> 15; x = (x * 0x846ca68b) & 0xffffffff
+        x ^= x >> 16
+        return x
+    key = (np.uint64(seed) + np.asarray(env, dtype=np.uint64) * 0x9E3779B9 + np.asarray(episode, dtype=np.uint64) * 0x85EBCA6B
+           + np.uint64(draw) * 0xC2B2AE35) & 0xffffffff
+    return (h(h(key)) >> 8).astype(np.float64) / 16777216.0
+
+
 # ------------------------------------------------------------------ the batched environment
 class BatchedAtacomEnv:
-    def __init__(self, spec, batch, init_q=None, init_dq=None, init_puck=None):
+    def __init__(self, spec, batch, init_q=None, init_dq=None, init_puck=None, random_init=False, seed=0):
         self.spec, self.B = spec, batch
+        self.random_init, self.seed = random_init, seed
+        self.episode = np.zeros(batch, dtype=np.int64)
         nq = spec.dim_q
         if init_q is None:
             init_q = {ENV_CIRCLE: np.array([-1.0, 0.0]), ENV_PLANAR: robots.PLANAR_INIT_Q,
@@ -204,6 +219,21 @@ class BatchedAtacomEnv:
         m = np.ones(self.B, dtype=bool) if mask is None else np.asarray(mask, dtype=bool)
         self.q[m], self.dq[m], self.puck[m] = self.init_q[m], self.init_dq[m], self.init_puck[m]
         self.has_hit[m], self.r_hit[m], self.vel_hit_x[m], self.t[m] = False, 0.0, 0.0, 0
+        if self.random_init and m.any():
+            env, ep = np.arange(self.B)[m], self.episode[m]
+            u = [device_uniform(self.seed, env, ep, i) for i in range(4)]
+            if self.spec.env_id == ENV_CIRCLE:              # circle_base.py:36-42
+                y = -0.5 + 1.5 * u[0]
+                x = np.sqrt(np.maximum(1 - y * y, 0)) * np.where(u[1] < 0.5, -1.0, 1.0)
+                dx = -1 + 2 * u[2]
+                dy = -x * dx / y
+                sp = u[3] / np.sqrt(dx * dx + dy * dy)
+                self.q[m] = np.stack([x, y], -1)
+                self.dq[m] = np.stack([dx * sp, dy * sp], -1)
+            else:                                           # env_hitting.py:24-25
+                self.puck[m, 0] = -0.6 + 0.4 * u[0]
+                self.puck[m, 1] = -0.4 + 0.8 * u[1]
+            self.episode[m] += 1
         if m.any():
             self.s[m] = self.slack_init(self.q[m], self.dq[m])
         return self.observation()

@@ -27,7 +27,7 @@ class AtacomConfig(C.Structure):
                 ('dt', C.c_double), ('rref_tol', C.c_double), ('action_penalty', C.c_double), ('gamma', C.c_double),
                 ('K', C.c_double * MAX_C), ('Kc', C.c_double * MAX_C), ('vel_max', C.c_double * MAX_Q),
                 ('acc_max', C.c_double * MAX_Q), ('Kq', C.c_double * MAX_Q), ('pos_limit', C.c_double * MAX_Q),
-                ('base_xy', C.c_double * 2), ('link', C.c_double * 3), ('term_tol', C.c_double)]
+                ('base_xy', C.c_double * 2), ('link', C.c_double * 3), ('term_tol', C.c_double), ('random_init', C.c_int32), ('seed', C.c_int32)]
 
 
 class AtacomMlp(C.Structure):

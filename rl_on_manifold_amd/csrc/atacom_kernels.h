@@ -27,7 +27,7 @@ struct Planes {
     static constexpr int Q = 0, DQ = Q + E::NQ, S = DQ + E::NQ, PUCK = S + E::NG, RHIT = PUCK + 6,
                          VHX = RHIT + 1, IQ = VHX + 1, IDQ = IQ + E::NQ, IS = IDQ + E::NQ, IPUCK = IS + E::NG,
                          SSUM = IPUCK + 6, SCMAX = SSUM + 1, SDQMAX = SCMAX + 1, COUNT = SDQMAX + 1;
-    static constexpr int I_HIT = 0, I_T = 1, I_CNT = 2, ICOUNT = 3;
+    static constexpr int I_HIT = 0, I_T = 1, I_CNT = 2, I_EP = 3, ICOUNT = 4;   // I_EP: episodes started (RNG counter)
     static constexpr int STATE_DIM = 2 * E::NQ + E::NG + 6 + 4;
     static constexpr int INIT_DIM = 2 * E::NQ + (E::PUCK ? 6 : 0);
 };
@@ -126,6 +126,48 @@ __device__ __forceinline__ void slack_init(const Params<T>& P, EnvState<T, E>& s
         for (int i = 0; i < E::NQ; ++i) jdq = num<T>::fma(J[r][i], st.dq[i], jdq);
         const T gv = num<T>::fma(P.K[r], jdq, fun[r]);
         st.s[g] = num<T>::sqrt(num<T>::max(T(-2) * gv, T(0)));
+    }
+}
+
+// ---- random initialisation on the device (A16, the random_init branches of circle_base.py:36-42 and
+// env_hitting.py:24-25).  The reference draws from numpy's global, unseeded generator, so only the distribution can
+// be matched; here the draws are a counter-based hash of (seed, env index, episode index, draw index), i.e. stateless,
+// reproducible, and identical in the oracle (oracle/atacom_batched.py: device_uniform).
+__device__ __forceinline__ unsigned int hash_u32(unsigned int x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+template <typename T>
+__device__ __forceinline__ T device_uniform(unsigned int seed, int env, int episode, int draw) {
+    const unsigned int key = seed + (unsigned int)env * 0x9E3779B9u + (unsigned int)episode * 0x85EBCA6Bu +
+                             (unsigned int)draw * 0xC2B2AE35u;
+    return (T)(hash_u32(hash_u32(key)) >> 8) * (T)(1.0 / 16777216.0);        // [0, 1) with 24 bits
+}
+
+// state <- stored initial state; with P.random_init the random part of the reference's reset is re-drawn and the
+// episode counter advances.  Returns with st.s valid (stored slack, or recomputed when q / dq were randomised).
+template <typename T, typename E>
+__device__ __forceinline__ void reset_env(const Params<T>& P, const T* __restrict__ f, int* __restrict__ ip, int B,
+                                          int b, EnvState<T, E>& st) {
+    using L = Planes<E>;
+    load_init<T, E>(f, B, b, st);
+    if (!P.random_init) return;
+    const int ep = ip[L::I_EP * (size_t)B + b];
+    ip[L::I_EP * (size_t)B + b] = ep + 1;
+    if (E::ID == 0) {
+        // circle_base.py:36-42
+        const T y = T(-0.5) + T(1.5) * device_uniform<T>(P.seed, b, ep, 0);
+        const T sg = (device_uniform<T>(P.seed, b, ep, 1) < T(0.5)) ? T(-1) : T(1);
+        const T x = num<T>::sqrt(num<T>::max(T(1) - y * y, T(0))) * sg;
+        const T dx = T(-1) + T(2) * device_uniform<T>(P.seed, b, ep, 2);
+        const T dy = -x * dx / y;
+        const T sp = device_uniform<T>(P.seed, b, ep, 3) / num<T>::sqrt(num<T>::fma(dx, dx, dy * dy));
+        st.q[0] = x; st.q[1] = y; st.dq[0] = dx * sp; st.dq[1] = dy * sp;
+        slack_init<T, E>(P, st);
+    } else {
+        // env_hitting.py:24-25: puck uniform in hit_range = [-0.6, -0.2] x [-0.4, 0.4] (env_hitting.py:11)
+        st.puck[0] = T(-0.6) + T(0.4) * device_uniform<T>(P.seed, b, ep, 0);
+        st.puck[1] = T(-0.4) + T(0.8) * device_uniform<T>(P.seed, b, ep, 1);
     }
 }
 
@@ -442,7 +484,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     f[L::SCMAX * (size_t)B + b] = num<T>::max(scmax0, out.log_max);
     f[L::SDQMAX * (size_t)B + b] = num<T>::max(sdq0, out.log_dq);
     ip[L::I_CNT * (size_t)B + b] = cnt0 + 1;
-    if (P.auto_reset && out.last) load_init<T, E>(f, B, b, st);
+    if (P.auto_reset && out.last) reset_env<T, E>(P, f, ip, B, b, st);
     store_state<T, E>(f, ip, B, b, st);
 }
 
@@ -481,7 +523,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
         ssum += out.log_avg;
         scmax = num<T>::max(scmax, out.log_max);
         sdq = num<T>::max(sdq, out.log_dq);
-        if (P.auto_reset && out.last) load_init<T, E>(f, B, b, st);
+        if (P.auto_reset && out.last) reset_env<T, E>(P, f, ip, B, b, st);
     }
     if (lq != 0) return;
     f[L::SSUM * (size_t)B + b] += ssum;
@@ -542,7 +584,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P,
         ssum += out.log_avg;
         scmax = num<T>::max(scmax, out.log_max);
         sdq = num<T>::max(sdq, out.log_dq);
-        if (P.auto_reset && out.last) load_init<T, E>(f, B, b, st);
+        if (P.auto_reset && out.last) reset_env<T, E>(P, f, ip, B, b, st);
     }
     if (lq != 0) return;
     f[L::SSUM * (size_t)B + b] += ssum;
@@ -576,9 +618,10 @@ __global__ void __launch_bounds__(WAVE) k_reset(const Params<T> P, T* __restrict
             }
         }
         load_init<T, E>(f, B, b, st);
-        slack_init<T, E>(P, st);
+        slack_init<T, E>(P, st);                 // slack of the STORED initial state (reused by every auto-reset)
 #pragma unroll
         for (int g = 0; g < E::NG; ++g) f[(L::IS + g) * (size_t)B + b] = st.s[g];
+        if (P.random_init && !init) reset_env<T, E>(P, f, ip, B, b, st);     // an explicit state wins over the draw
         store_state<T, E>(f, ip, B, b, st);
     } else {
         load_state<T, E>(f, ip, B, b, st);

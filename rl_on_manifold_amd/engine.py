@@ -33,7 +33,7 @@ class BatchedAtacomEnv:
 
     def __init__(self, env, batch, device='cuda:0', dtype=torch.float32, horizon=None, gamma=None, Kc=None,
                  time_step=None, n_intermediate_steps=None, action_penalty=None, auto_reset=False,
-                 hold_q=None, bias_mode='reference', rref_tol=None, lanes_per_env=0, term_tol=None):
+                 hold_q=None, bias_mode='reference', rref_tol=None, lanes_per_env=0, term_tol=None, random_init=False, seed=0):
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.AtacomError("BatchedAtacomEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -65,6 +65,8 @@ class BatchedAtacomEnv:
         cfg.lanes_per_env = int(lanes_per_env)      # 0 auto, 1 lane-per-env, 4 quad-per-env kernels
         if term_tol is not None:
             cfg.term_tol = float(term_tol)
+        cfg.random_init = int(bool(random_init))     # device-side random reset (circle_base.py:36-42, env_hitting.py:24-25)
+        cfg.seed = int(seed) & 0x7fffffff
         d = _lib.get_dims(self.env_id)
         self.dims = {'q': d.dim_q, 'f': d.n_f, 'g': d.n_g, 'null': d.n_null, 'c': d.n_f + d.n_g}   # atacom.py:25-40
         self.obs_dim, self.state_dim, self.init_state_dim = d.obs_dim, d.state_dim, d.init_state_dim

@@ -513,3 +513,42 @@ def test_kc_vector_and_time_step_overrides():
         env.set_state(_full_state(env, o))
         obs = env.step(a)[0].cpu().numpy()
         assert np.abs(obs - o.step(a)[0]).max() < 1e-9
+
+
+@pytest.mark.parametrize('name', ['circle', 'planar', 'iiwa'])
+def test_device_random_init_matches_oracle_generator(name):
+    """A16, random branch of the reference's reset (circle_base.py:36-42, env_hitting.py:24-25) drawn ON the device with
+    the counter-based generator; the oracle restates the generator, so states agree draw for draw, reset after reset."""
+    spec = SPECS[name]()
+    B, horizon = 300, 3
+    spec.horizon = horizon
+    env = _env(name, B, 'f64', random_init=True, seed=77, auto_reset=True, horizon=horizon)
+    o = ob.BatchedAtacomEnv(spec, B, init_q=env.get_state().cpu().numpy()[0, :spec.dim_q] if name != 'circle' else None,
+                            random_init=True, seed=77)
+    o.reset(); o.episode[:] = 1; o.reset()                     # engine: create() resets once, the ctor's reset() again
+    obs0 = env.reset().cpu().numpy()
+    o.reset()
+    assert np.allclose(obs0, o.observation(), atol=1e-12)
+    if name == 'circle':
+        assert np.allclose((obs0[:, :2] ** 2).sum(1), 1.0) and np.abs((obs0[:, :2] * obs0[:, 2:]).sum(1)).max() < 1e-12
+        assert len(np.unique(np.round(obs0[:, 1], 6))) > 250
+    else:
+        px, py = obs0[:, 0] + spec.base_xy[0], obs0[:, 1] + spec.base_xy[1]
+        assert (px >= -0.6).all() and (px <= -0.2).all() and (py >= -0.4).all() and (py <= 0.4).all()
+        assert px.std() > 0.08 and py.std() > 0.15
+    # auto-reset inside the rollout kernel re-draws with the next episode index
+    rng = np.random.default_rng(2)
+    acts = rng.uniform(-1, 1, (2 * horizon + 1, B, spec.action_dim))
+    out = env.rollout(torch.tensor(acts))
+    for t in range(acts.shape[0]):
+        got, want = out['obs'][t].cpu().numpy(), o.observation()
+        # the drawn part (puck / circle state at a reset) must agree exactly; the arm is free-running from the exact
+        # reset pose, which sits on a discontinuity of the reference algorithm (DESIGN.md section 2), so it is loose
+        ncmp = 4 if name == 'circle' else 6
+        assert np.allclose(got[:, :ncmp], want[:, :ncmp], atol=1e-6 if name == 'circle' else 1e-9), t
+        assert np.abs(got - want).max() < 5e-2, t
+        _, _, ab, _ = o.step(acts[t])
+        last = ab | (o.t >= horizon)
+        if last.any():
+            o.reset(last)
+    assert not np.allclose(out['obs'][horizon].cpu().numpy()[:, :2], out['obs'][0].cpu().numpy()[:, :2])

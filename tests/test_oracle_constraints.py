@@ -43,3 +43,15 @@ def test_log_aggregation(golden):
     out = env.get_constraints_logs()
     assert np.allclose(out, g['agg_out'], atol=1e-14)
     assert env.logs == []                                   # cleared, atacom.py:213
+
+
+def test_device_generator_restatement_statistics():
+    """The counter-based generator used for on-device random resets: uniform, decorrelated across env / episode / draw."""
+    u = ob.device_uniform(3, np.arange(200000), 0, 0)
+    assert abs(u.mean() - 0.5) < 3e-3 and abs(u.std() - 12 ** -0.5) < 3e-3 and u.min() >= 0 and u.max() < 1
+    v = ob.device_uniform(3, np.arange(200000), 1, 0)
+    w = ob.device_uniform(3, np.arange(200000), 0, 1)
+    assert abs(np.corrcoef(u, v)[0, 1]) < 0.01 and abs(np.corrcoef(u, w)[0, 1]) < 0.01
+    env = ob.BatchedAtacomEnv(osc.circle_spec(), 64, random_init=True, seed=1)
+    assert np.allclose((env.q ** 2).sum(1), 1) and np.abs((env.q * env.dq).sum(1)).max() < 1e-12
+    assert (env.q[:, 1] >= -0.5).all() and (np.linalg.norm(env.dq, axis=1) <= 1).all()
