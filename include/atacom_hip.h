@@ -137,6 +137,13 @@ typedef struct atacom_mlp {
     const void *W1, *b1, *W2, *b2, *W3, *b3;
     const void *obs_shift, *obs_scale; /* [n_in], may be NULL (identity) */
     const void *std;                   /* [n_out], may be NULL (deterministic) */
+    /* optional SAC-style policy (examples/iiwa_air_hockey_exp.py:301-339: actor_mu + actor_sigma networks of the same
+     * architecture): a second network giving log(sigma) per action dim, clamped to [log_std_min, log_std_max], replaces
+     * `std`; squash = 1 applies tanh to mean + sigma * eps (the squashed Gaussian SAC samples from). */
+    const void *sW1, *sb1, *sW2, *sb2, *sW3, *sb3; /* all NULL = no sigma network */
+    double log_std_min, log_std_max;               /* MushroomRL's SACPolicy uses -20, 2 */
+    int32_t squash;
+    int32_t reserved1;
 } atacom_mlp;
 
 /* Like atacom_rollout, with d_actions [n_steps, batch, n_out] an OUTPUT (the actions the policy drew). */

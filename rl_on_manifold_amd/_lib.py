@@ -36,7 +36,10 @@ class AtacomMlp(C.Structure):
                 ('activation', C.c_int32), ('reserved', C.c_int32),
                 ('W1', C.c_void_p), ('b1', C.c_void_p), ('W2', C.c_void_p), ('b2', C.c_void_p),
                 ('W3', C.c_void_p), ('b3', C.c_void_p), ('obs_shift', C.c_void_p), ('obs_scale', C.c_void_p),
-                ('std', C.c_void_p)]
+                ('std', C.c_void_p),
+                ('sW1', C.c_void_p), ('sb1', C.c_void_p), ('sW2', C.c_void_p), ('sb2', C.c_void_p),
+                ('sW3', C.c_void_p), ('sb3', C.c_void_p), ('log_std_min', C.c_double), ('log_std_max', C.c_double),
+                ('squash', C.c_int32), ('reserved1', C.c_int32)]
 
 
 class AtacomDims(C.Structure):

@@ -249,6 +249,10 @@ int atacom_rollout_mlp(atacom_handle* h, int32_t n_steps, const atacom_mlp* net,
         return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: network n_in / n_out must equal obs_dim / n_null");
     if (!net->W1 || !net->b1 || !net->W2 || !net->b2 || !net->W3 || !net->b3)
         return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: null weight pointer");
+    const int n_sig = (net->sW1 != nullptr) + (net->sb1 != nullptr) + (net->sW2 != nullptr) + (net->sb2 != nullptr) +
+                      (net->sW3 != nullptr) + (net->sb3 != nullptr);
+    if (n_sig != 0 && n_sig != 6)
+        return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: the sigma network needs all six weight pointers (or none)");
     if (net->activation != 0 && net->activation != 1)
         return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: activation must be 0 (ReLU) or 1 (tanh)");
     if (!d_obs || !d_actions || !d_reward || !d_absorbing || !d_last)

@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P,
     using L = Planes<E>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* lds = reinterpret_cast<T*>(smem);
-    T* park = lds + ((MlpLds<E::OBS, H, E::NK>::TOTAL + 3) / 4) * 4 + threadIdx.x;
+    T* park = lds + ((2 * MlpLds<E::OBS, H, E::NK>::TOTAL + 3) / 4) * 4 + threadIdx.x;
     mlp_stage<T, E::OBS, H, E::NK>(net, lds, threadIdx.x, BLOCK<LANES>);
     const int B = P.batch;
     const int gt = blockIdx.x * BLOCK<LANES> + threadIdx.x;
@@ -561,11 +561,23 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P,
         T o[E::OBS];
         write_obs<T, E>(P, st, o);
         T act[E::NK];
-        mlp_forward<T, E::OBS, H, E::NK, LANES>(lds, o, net.activation, lq, act);
+        mlp_forward<T, E::OBS, H, E::NK, LANES>(lds, lds, o, net.activation, lq, act);
+        T sig[E::NK];
+        if (net.sW1) {
+            // state-dependent sigma = exp(clamp(log_sigma_net(obs)))   (SAC)
+            mlp_forward<T, E::OBS, H, E::NK, LANES>(lds + MlpLds<E::OBS, H, E::NK>::TOTAL, lds, o, net.activation, lq, sig);
+#pragma unroll
+            for (int k = 0; k < E::NK; ++k)
+                sig[k] = num<T>::exp(num<T>::min(num<T>::max(sig[k], net.log_std_min), net.log_std_max));
+        } else {
+#pragma unroll
+            for (int k = 0; k < E::NK; ++k) sig[k] = lds[MlpLds<E::OBS, H, E::NK>::STD + k];
+        }
 #pragma unroll
         for (int k = 0; k < E::NK; ++k) {
             const T eps = noise ? noise[row * E::NK + k] : T(0);
-            act[k] = num<T>::fma(lds[MlpLds<E::OBS, H, E::NK>::STD + k], eps, act[k]);
+            act[k] = num<T>::fma(sig[k], eps, act[k]);
+            if (net.squash) act[k] = tanh(act[k]);
         }
         if (lq == 0) {
 #pragma unroll

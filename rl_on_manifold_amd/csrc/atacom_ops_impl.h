@@ -86,7 +86,7 @@ struct Ops {
                            const void* noise, void* obs, void* nobs, void* acts, void* rew, uint8_t* ab,
                            uint8_t* last, hipStream_t s) {
         constexpr int H = 64;
-        const size_t lds_bytes = sizeof(T) * (((MlpLds<E::OBS, H, E::NK>::TOTAL + 3) / 4) * 4) + park_bytes<T, E, LANES>();
+        const size_t lds_bytes = sizeof(T) * (((2 * MlpLds<E::OBS, H, E::NK>::TOTAL + 3) / 4) * 4) + park_bytes<T, E, LANES>();
         hipLaunchKernelGGL((k_rollout_mlp<T, E, LANES, HOLD, H>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)),
                            dim3(BLOCK<LANES>),
                            lds_bytes, s, make_params<T>(c), a, n_steps, (T*)f, ip, (const T*)noise, (T*)obs, (T*)nobs,
@@ -100,6 +100,9 @@ struct Ops {
         a.W1 = (const T*)net.W1; a.b1 = (const T*)net.b1; a.W2 = (const T*)net.W2; a.b2 = (const T*)net.b2;
         a.W3 = (const T*)net.W3; a.b3 = (const T*)net.b3; a.obs_shift = (const T*)net.obs_shift;
         a.obs_scale = (const T*)net.obs_scale; a.std = (const T*)net.std;
+        a.sW1 = (const T*)net.sW1; a.sb1 = (const T*)net.sb1; a.sW2 = (const T*)net.sW2; a.sb2 = (const T*)net.sb2;
+        a.sW3 = (const T*)net.sW3; a.sb3 = (const T*)net.sb3;
+        a.log_std_min = (T)net.log_std_min; a.log_std_max = (T)net.log_std_max; a.squash = net.squash;
         a.n_in = net.n_in; a.n_out = net.n_out; a.activation = net.activation;
         if constexpr (E::ID != 0) {
             if (lanes == 4) {

@@ -25,7 +25,12 @@ struct MlpArgs {
     const T *W1, *b1, *W2, *b2, *W3, *b3;   // torch.nn.Linear layout: W[out][in]
     const T *obs_shift, *obs_scale;          // x = (obs - shift) * scale      (nullable: identity)
     const T *std;                            // exploration std per action dim (nullable: 0)
+    // optional second network of the same shape producing log(sigma) per action dim (SAC: actor_sigma_params,
+    // examples/iiwa_air_hockey_exp.py:310-314); when present it replaces `std`
+    const T *sW1, *sb1, *sW2, *sb2, *sW3, *sb3;
+    T log_std_min, log_std_max;              // clamp of the sigma network's output (MushroomRL SACPolicy: -20, 2)
     int n_in, n_out, activation;             // activation: 0 ReLU, 1 tanh
+    int squash;                              // 1: action = tanh(mean + sigma * eps)   (SAC's squashed Gaussian)
 };
 
 template <int D, int H, int NK>
@@ -40,18 +45,27 @@ struct MlpLds {
 
 // cooperative staging by the whole workgroup (call before any early return)
 template <typename T, int D, int H, int NK>
+__device__ __forceinline__ void mlp_stage_weights(T* lds, const T* W1, const T* b1, const T* W2, const T* b2,
+                                                  const T* W3, const T* b3, int tid, int nthreads) {
+    using L = MlpLds<D, H, NK>;
+    for (int i = tid; i < H * D; i += nthreads) lds[L::W1 + (i / D) * L::S1 + (i % D)] = W1[i];
+    for (int i = tid; i < H * H; i += nthreads) lds[L::W2 + (i / H) * L::S2 + (i % H)] = W2[i];
+    for (int i = tid; i < NK * H; i += nthreads) lds[L::W3T + (i % H) * L::S3 + (i / H)] = W3[i];
+    for (int i = tid; i < H; i += nthreads) { lds[L::B1 + i] = b1[i]; lds[L::B2 + i] = b2[i]; }
+    for (int i = tid; i < NK; i += nthreads) lds[L::B3 + i] = b3[i];
+}
+
+// LDS holds one MlpLds block for the mean network and, if present, a second one for the sigma network
+template <typename T, int D, int H, int NK>
 __device__ __forceinline__ void mlp_stage(const MlpArgs<T>& net, T* lds, int tid, int nthreads) {
     using L = MlpLds<D, H, NK>;
-    for (int i = tid; i < L::TOTAL; i += nthreads) lds[i] = T(0);
+    const int total = net.sW1 ? 2 * L::TOTAL : L::TOTAL;
+    for (int i = tid; i < total; i += nthreads) lds[i] = T(0);
     __syncthreads();
-    for (int i = tid; i < H * D; i += nthreads) lds[L::W1 + (i / D) * L::S1 + (i % D)] = net.W1[i];
-    for (int i = tid; i < H * H; i += nthreads) lds[L::W2 + (i / H) * L::S2 + (i % H)] = net.W2[i];
-    for (int i = tid; i < NK * H; i += nthreads) lds[L::W3T + (i % H) * L::S3 + (i / H)] = net.W3[i];
-    for (int i = tid; i < H; i += nthreads) { lds[L::B1 + i] = net.b1[i]; lds[L::B2 + i] = net.b2[i]; }
-    for (int i = tid; i < NK; i += nthreads) {
-        lds[L::B3 + i] = net.b3[i];
-        lds[L::STD + i] = net.std ? net.std[i] : T(0);
-    }
+    mlp_stage_weights<T, D, H, NK>(lds, net.W1, net.b1, net.W2, net.b2, net.W3, net.b3, tid, nthreads);
+    if (net.sW1)
+        mlp_stage_weights<T, D, H, NK>(lds + L::TOTAL, net.sW1, net.sb1, net.sW2, net.sb2, net.sW3, net.sb3, tid, nthreads);
+    for (int i = tid; i < NK; i += nthreads) lds[L::STD + i] = net.std ? net.std[i] : T(0);
     for (int i = tid; i < D; i += nthreads) {
         lds[L::SHIFT + i] = net.obs_shift ? net.obs_shift[i] : T(0);
         lds[L::SCALE + i] = net.obs_scale ? net.obs_scale[i] : T(1);
@@ -66,13 +80,13 @@ __device__ __forceinline__ T mlp_act(T v, int activation) {
 
 // mean action of the policy for one env: x = normalised observation (replicated in the quad)
 template <typename T, int D, int H, int NK, int LANES>
-__device__ __forceinline__ void mlp_forward(const T* __restrict__ lds, const T (&obs)[D], int activation, int lq,
-                                            T (&mean)[NK]) {
+__device__ __forceinline__ void mlp_forward(const T* __restrict__ lds, const T* __restrict__ lds_norm,
+                                            const T (&obs)[D], int activation, int lq, T (&mean)[NK]) {
     using L = MlpLds<D, H, NK>;
     constexpr int U = H / LANES;
     T x[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) x[i] = (obs[i] - lds[L::SHIFT + i]) * lds[L::SCALE + i];
+    for (int i = 0; i < D; ++i) x[i] = (obs[i] - lds_norm[L::SHIFT + i]) * lds_norm[L::SCALE + i];
     T h1[U];
 #pragma unroll
     for (int m = 0; m < U; ++m) {

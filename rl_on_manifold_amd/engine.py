@@ -208,10 +208,26 @@ class MlpPolicy:
     names of the reference's PPONetwork / TRPONetwork / SACActorNetwork (examples/network.py:19-21,50-52,277-279).
     obs_low / obs_high give the MinMaxPreprocessor normalisation x = (obs - mean) / delta of the finite bounds."""
 
-    def __init__(self, W1, b1, W2, b2, W3, b3, std=None, obs_shift=None, obs_scale=None, activation='relu'):
+    def __init__(self, W1, b1, W2, b2, W3, b3, std=None, obs_shift=None, obs_scale=None, activation='relu',
+                 sigma_weights=None, squash=False, log_std_min=-20.0, log_std_max=2.0):
         self.tensors = dict(W1=W1, b1=b1, W2=W2, b2=b2, W3=W3, b3=b3, std=std, obs_shift=obs_shift, obs_scale=obs_scale)
+        if sigma_weights is not None:                     # SAC: second network -> log sigma
+            self.tensors.update(dict(zip(('sW1', 'sb1', 'sW2', 'sb2', 'sW3', 'sb3'), sigma_weights)))
         self.activation = {'relu': 0, 'tanh': 1}[activation]
+        self.squash, self.log_std_min, self.log_std_max = bool(squash), float(log_std_min), float(log_std_max)
         self._keep = None
+
+    @classmethod
+    def from_sac(cls, mu_net, sigma_net, obs_low=None, obs_high=None, log_std_min=-20.0, log_std_max=2.0):
+        """The squashed-Gaussian policy SAC samples from: mean and log-sigma networks of the reference's
+        SACActorNetwork (examples/network.py:266-293, examples/iiwa_air_hockey_exp.py:301-314), action =
+        tanh(mu(obs) + exp(clamp(log_sigma(obs))) * eps)."""
+        pol = cls.from_module(mu_net, obs_low=obs_low, obs_high=obs_high)
+        g = lambda lin: (lin.weight.detach(), lin.bias.detach())      # noqa: E731
+        sw = [t for lin in (sigma_net._h1, sigma_net._h2, sigma_net._h3) for t in g(lin)]
+        pol.tensors.update(dict(zip(('sW1', 'sb1', 'sW2', 'sb2', 'sW3', 'sb3'), sw)))
+        pol.squash, pol.log_std_min, pol.log_std_max = True, float(log_std_min), float(log_std_max)
+        return pol
 
     @classmethod
     def from_module(cls, net, std=None, obs_low=None, obs_high=None, activation='relu'):
@@ -236,8 +252,11 @@ class MlpPolicy:
         if tuple(dev['W2'].shape) != (m.hidden, m.hidden) or dev['W3'].shape[1] != m.hidden:
             raise ValueError("expected Linear(n_in,h) - Linear(h,h) - Linear(h,n_out)")
         m.activation = self.activation
-        for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3', 'obs_shift', 'obs_scale', 'std'):
-            setattr(m, k, None if dev[k] is None else dev[k].data_ptr())
+        for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3', 'obs_shift', 'obs_scale', 'std', 'sW1', 'sb1', 'sW2', 'sb2',
+                  'sW3', 'sb3'):
+            v = dev.get(k)
+            setattr(m, k, None if v is None else v.data_ptr())
+        m.squash, m.log_std_min, m.log_std_max = int(self.squash), self.log_std_min, self.log_std_max
         return m
 
 

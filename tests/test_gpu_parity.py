@@ -288,6 +288,45 @@ def test_policy_rollout_against_oracle(golden, name, key, dt, lanes):
         assert np.median(errs) < 5e-5 and (errs < 3e-3).mean() >= 0.98, (np.median(errs), (errs < 3e-3).mean())
 
 
+@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('dt', ['f64', 'f32'])
+def test_sac_style_policy_rollout_against_oracle(golden, dt, lanes):
+    """The reference's default agent is SAC (examples/iiwa_air_hockey_exp.py:345): mean and log-sigma networks
+    (SACActorNetwork) and a tanh-squashed sample.  Fused in the rollout kernel vs the oracle."""
+    from rl_on_manifold_amd import MlpPolicy
+    from oracle.policy import MlpPolicy as OraclePolicy, rollout as oracle_rollout
+    g = golden('policy_net')
+    W = [g['sac_planar._h%d.%s' % (i, w)] for i in (1, 2, 3) for w in ('weight', 'bias')]
+    rng = np.random.default_rng(31)
+    Ws = [w * 0.5 + rng.normal(0, 0.05, w.shape) for w in W]           # a different network for log sigma
+    Ws[5] = Ws[5] - 1.0
+    shift, scale = rng.uniform(-0.5, 0.5, 12), rng.uniform(0.5, 2.0, 12)
+    dev = MlpPolicy(*[torch.tensor(w) for w in W], obs_shift=torch.tensor(shift), obs_scale=torch.tensor(scale),
+                    sigma_weights=[torch.tensor(w) for w in Ws], squash=True, log_std_min=-3.0, log_std_max=0.5)
+    ora = OraclePolicy(*W, obs_shift=shift, obs_scale=scale, sigma_weights=Ws, squash=True, log_std_min=-3.0,
+                       log_std_max=0.5)
+    spec = SPECS['planar']()
+    B = 256
+    env = _env('planar', B, dt, lanes_per_env=lanes)
+    init_q = env.get_state().cpu().numpy().astype(np.float64)[:, :3] + rng.normal(0, 0.05, (B, 3))
+    o = ob.BatchedAtacomEnv(spec, B, init_q=init_q)
+    errs = []
+    for t in range(10):
+        eps = rng.standard_normal((1, B, 3))
+        env.set_state(_full_state(env, o))
+        out = env.rollout_policy(dev, 1, noise=torch.tensor(eps))
+        ref = oracle_rollout(o, ora, 1, noise=eps, auto_reset=False)
+        a = out['action'][0].cpu().numpy()
+        assert np.abs(a).max() <= 1.0                                   # squashed
+        errs.append(np.maximum(np.abs(a - ref['action'][0]).max(1),
+                               np.abs(out['next_obs'][0].cpu().numpy() - ref['next_obs'][0]).max(1)))
+    errs = np.array(errs)
+    assert (errs.max() < 1e-8) if dt == 'f64' else (np.median(errs) < 5e-5 and (errs < 3e-3).mean() >= 0.98)
+    # clamp really active somewhere, sigma really state dependent
+    sg = ora.sigma(o.observation())
+    assert sg.std() > 1e-3 and sg.min() >= np.exp(-3.0) - 1e-12 and sg.max() <= np.exp(0.5) + 1e-12
+
+
 def test_policy_rollout_multi_step_consistency(golden):
     """T-step policy rollout == feeding the actions it drew to the plain rollout kernel; deterministic without noise."""
     B, T = 192, 10
