@@ -190,99 +190,111 @@ __device__ __forceinline__ void bidiag_solve_null_quad(T (&a)[M][(N + 3) / 4], T
     });
 }
 
-// Chart (rref + Nc @ alpha) on the column-split null basis.  Measured on MI355X: for the
-// quad mapping the literal Gauss-Jordan below beats the T-matrix formulation used by the one-lane mapping
-// (atacom_linalg.h: ChartState) -- the latter is a serial dependency chain per column, whereas here the K x S
-// updates of a pivot step are independent across slots and lanes and a lone wave is latency-, not issue-bound.
-// Semantics: null_space_coordinate.py:40-79 with row_vectors=False; rows are not physically swapped, each row
-// records the order in which it became a pivot row.
+// Chart (rref + Nc @ alpha) on the column-split null basis.
+// Semantics: null_space_coordinate.py:40-79 with row_vectors=False (scan the columns left to right; a column
+// whose largest entry over the not-yet-pivot rows is <= tol is skipped and those entries are zeroed; otherwise
+// the arg-max row becomes the next pivot row, is scaled to 1 and eliminated from every other row; stop after K
+// pivots).
+//
+// Formulated as K PIVOT ROUNDS instead of N column steps.  Between two pivots the matrix does not change
+// (a skip only zeroes entries of the skipped column), so "the next pivot column" is simply the first column
+// >= j0 whose masked column-max exceeds tol -- all columns are tested at once (each lane its own slots, one
+// quad-min), and the cost is a fixed K rounds with no data-dependent trip count: the column-by-column form
+// spent most of its time in the ~11% of environments that walk almost all N columns looking for their last
+// pivot, and a wavefront runs as long as its slowest quad.
+//   * the skip-zeroing is never materialised: eliminations are gated to columns >= the pivot column, so a
+//     skipped column is frozen from the moment it is passed, and the final contraction only takes, for
+//     column c, the rows that were already pivot rows when c was passed (jrow[r] <= c);
+//   * rows are not physically swapped: row r remembers the column jrow[r] at which it became a pivot row and
+//     the action component ar[r] = alpha[round] that the reference's row order pairs it with;
+//   * the pivot-row scaling and the elimination are one fused update  row_r -= g_r * (row_p / pivot)  with
+//     g_p = pivot - 1, which leaves no per-element select in the K x S inner loop.
 // out[slot] = (Nc @ alpha)[4*slot + lq].
 template <typename T, int N, int K>
 __device__ __forceinline__ void rref_apply_quad(T (&nb)[(N + 3) / 4][K], const T (&alpha)[K], T tol,
                                                 T (&out)[(N + 3) / 4], const int lq) {
     constexpr int S = (N + 3) / 4;
-    int order[K];
+    constexpr int BIG = 1 << 20;
+    int col[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) col[s] = 4 * s + lq;
     bool used[K];
-#pragma unroll
-    for (int r = 0; r < K; ++r) { order[r] = -1; used[r] = false; }
-    int cnt = 0;
-    static_for<0, N>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        constexpr int sj = j / 4, lj = j % 4;
-        const bool active = cnt < K;
-        if (__builtin_amdgcn_ballot_w64(active) != 0ull) {
-            // column j lives in slot sj of lane lj: every lane evaluates its own slot-sj column, the
-            // owner's answer is broadcast
-            T p = T(-1);
-            int kk = 0;
-            T pj = T(0);
-#pragma unroll
-            for (int r = 0; r < K; ++r) {
-                const T av = used[r] ? T(-1) : num<T>::abs(nb[sj][r]);
-                const bool gt = av > p;
-                p = gt ? av : p;
-                kk = gt ? r : kk;
-                pj = gt ? nb[sj][r] : pj;
-            }
-            T f[K];
-            if (lj == 0) { p = qbcast<0>(p); kk = qbcast<0>(kk); pj = qbcast<0>(pj); }
-            else if (lj == 1) { p = qbcast<1>(p); kk = qbcast<1>(kk); pj = qbcast<1>(pj); }
-            else if (lj == 2) { p = qbcast<2>(p); kk = qbcast<2>(kk); pj = qbcast<2>(pj); }
-            else { p = qbcast<3>(p); kk = qbcast<3>(kk); pj = qbcast<3>(pj); }
-#pragma unroll
-            for (int r = 0; r < K; ++r) {
-                f[r] = (lj == 0) ? qbcast<0>(nb[sj][r]) : (lj == 1) ? qbcast<1>(nb[sj][r])
-                     : (lj == 2) ? qbcast<2>(nb[sj][r]) : qbcast<3>(nb[sj][r]);
-            }
-            const bool piv = active && (p > tol);
-            const bool skip = active && !piv;
-            const T inv = piv ? num<T>::rcp(pj) : T(0);
-            const bool own = (lq == lj);
-#pragma unroll
-            for (int r = 0; r < K; ++r) {
-                const bool is_p = piv && (r == kk);
-                // column j itself (owner lane only): pivot row -> 1, others -> 0, skipped -> 0 on unused rows
-                const T cur = nb[sj][r];
-                const T newj = is_p ? T(1) : ((piv || (skip && !used[r])) ? T(0) : cur);
-                nb[sj][r] = own ? newj : cur;
-                f[r] = (piv && !is_p) ? f[r] : T(0);
-            }
-#pragma unroll
-            for (int s = sj; s < S; ++s) {
-                const bool cgt = (s > sj) || (lq > lj);            // this lane's column 4*s+lq is > j
-                T pr = T(0);
-#pragma unroll
-                for (int r = 0; r < K; ++r) pr = (r == kk) ? nb[s][r] : pr;
-                pr *= inv;
-#pragma unroll
-                for (int r = 0; r < K; ++r) {
-                    const bool is_p = piv && (r == kk);
-                    const T upd = is_p ? pr : num<T>::fma(-f[r], pr, nb[s][r]);
-                    nb[s][r] = cgt ? upd : nb[s][r];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < K; ++r) {
-                const bool is_p = piv && (r == kk);
-                order[r] = is_p ? cnt : order[r];
-                used[r] = used[r] || is_p;
-            }
-            cnt += piv ? 1 : 0;
-        }
-    });
+    int jrow[K];
     T ar[K];
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
-        T v = T(0);
+    for (int r = 0; r < K; ++r) { used[r] = false; jrow[r] = BIG; ar[r] = T(0); }
+    int j0 = 0;
+    static_for<0, K>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        // ---- next pivot column: first column >= j0 with max |entry| over the unused rows > tol
+        int cand = BIG;
 #pragma unroll
-        for (int k = 0; k < K; ++k) v = (order[r] == k) ? alpha[k] : v;
-        ar[r] = v;
-    }
+        for (int s = S - 1; s >= 0; --s) {
+            T cm = T(0);
+#pragma unroll
+            for (int r = 0; r < K; ++r) cm = num<T>::max(cm, used[r] ? T(0) : num<T>::abs(nb[s][r]));
+            const bool e = (cm > tol) && (col[s] >= j0);
+            cand = e ? col[s] : cand;
+        }
+        int jmin = min(cand, dpp_mov<0xB1>(cand));
+        jmin = min(jmin, dpp_mov<0x4E>(jmin));
+        const bool found = jmin < BIG;
+        // ---- that column's K entries, replicated over the quad (zeros when no column was found)
+        T w[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) w[s] = (col[s] == jmin) ? T(1) : T(0);
+        T f[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            T v = w[0] * nb[0][r];
+#pragma unroll
+            for (int s = 1; s < S; ++s) v = num<T>::fma(w[s], nb[s][r], v);
+            f[r] = qsum(v);
+        }
+        // ---- pivot row: first arg-max of |f| over the unused rows
+        T p = T(-1);
+#pragma unroll
+        for (int r = 0; r < K; ++r) p = num<T>::max(p, used[r] ? T(-1) : num<T>::abs(f[r]));
+        bool isp[K];
+        bool taken = !found;
+        T pj = T(1);
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            const bool m = !used[r] && (num<T>::abs(f[r]) == p);
+            isp[r] = m && !taken;
+            taken = taken || m;
+            pj = isp[r] ? f[r] : pj;
+        }
+        const T inv = num<T>::rcp(pj);
+        T oh[K], g[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            oh[r] = isp[r] ? inv : T(0);
+            g[r] = isp[r] ? f[r] - T(1) : f[r];
+        }
+        // ---- scaled pivot row (zero left of the pivot column and when nothing was found), fused update
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            T pr = oh[0] * nb[s][0];
+#pragma unroll
+            for (int r = 1; r < K; ++r) pr = num<T>::fma(oh[r], nb[s][r], pr);
+            pr = (col[s] >= jmin) ? pr : T(0);
+#pragma unroll
+            for (int r = 0; r < K; ++r) nb[s][r] = num<T>::fma(-g[r], pr, nb[s][r]);
+        }
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+            used[r] = used[r] || isp[r];
+            jrow[r] = isp[r] ? jmin : jrow[r];
+            ar[r] = isp[r] ? alpha[t] : ar[r];
+        }
+        j0 = jmin + 1;
+    });
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         T v = T(0);
 #pragma unroll
-        for (int r = 0; r < K; ++r) v = num<T>::fma(ar[r], nb[s][r], v);
+        for (int r = 0; r < K; ++r) v = num<T>::fma((jrow[r] <= col[s]) ? ar[r] : T(0), nb[s][r], v);
         out[s] = v;
     }
 }
