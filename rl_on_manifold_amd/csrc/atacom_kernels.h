@@ -240,8 +240,9 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) {
                     jdq = num<T>::fma(J[r][i], dqc[i], jdq);
-                    const T kj = P.K[r] * J[r][i];              // constraints.py:39-40
-                    A[r][i] = (kj == T(0)) ? T(0) : kj;         // -0 -> +0 (the reference's matmul does the same)
+                    // constraints.py:39-40; the "+ 0" inside the FMA turns a -0 product into +0 exactly as the
+                    // reference's diag(K) @ J matmul does (the sign of a zero steers dlarfg's sign choice)
+                    A[r][i] = num<T>::fma(P.K[r], J[r][i], T(0));
                 }
                 psi[r] = num<T>::fma(P.K[r], bst[r], jdq);      // constraints.py:42-43
                 c0[r] = num<T>::fma(P.K[r], jdq, fun[r]);       // constraints.py:33-37
@@ -310,22 +311,23 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
         } else {
             constexpr int S = (NN + 3) / 4;
             constexpr int ND = NN - NC;
-            T a[NC][S], x[S], nb[S][ND], nmu[S];
+            T x[S], nb[S][ND], nmu[S];
             T alphaq[ND];
 #pragma unroll
             for (int k = 0; k < ND; ++k) alphaq[k] = alpha[k < NK ? k : 0];
             // this lane's columns: the K J block was split once per step (Aq), the slack diagonal entry of
             // row r sits in column NQ + r - NF, i.e. slot (NQ+r-NF)/4 of lane (NQ+r-NF)%4
-#pragma unroll
-            for (int r = 0; r < NC; ++r) {
-#pragma unroll
-                for (int sl = 0; sl < S; ++sl) a[r][sl] = Aq[r][sl];
-                if (r >= NF) {
-                    const int c = NQ + r - NF;
-                    a[r][c / 4] = (lq == c % 4) ? st.s[r >= NF ? r - NF : 0] : Aq[r][c / 4];
+            auto aget = [&](auto rc, auto sc) -> T {
+                constexpr int r = decltype(rc)::value, sl = decltype(sc)::value;
+                const T base = Aq[r][sl];
+                if constexpr (r >= NF) {
+                    constexpr int c = NQ + r - NF;
+                    if constexpr (c / 4 == sl) return (lq == c % 4) ? st.s[r - NF] : base;
                 }
-            }
-            bidiag_solve_null_quad<T, NC, NN>(a, y, x, nb, lq);
+                return base;
+            };
+            auto yget = [&](auto rc) -> T { return y[decltype(rc)::value]; };
+            bidiag_solve_null_quad<T, NC, NN>(aget, yget, x, nb, lq);
             rref_apply_quad<T, NN, ND>(nb, alphaq, P.rref_tol, nmu, lq);
 #pragma unroll
             for (int n = 0; n < NN; ++n) {                          // gather mu back to every lane of the quad
@@ -794,17 +796,14 @@ __global__ void __launch_bounds__(WAVE) k_nullspace_quad(int n, const T* __restr
     const int gt = blockIdx.x * WAVE + threadIdx.x;
     const int b = gt >> 2, lq = gt & 3;
     if (b >= n) return;
-    T a[NC][S], y[NC], x[S], nb[S][NK];
-#pragma unroll
-    for (int r = 0; r < NC; ++r) {
-        y[r] = rhs ? rhs[(size_t)b * NC + r] : T(0);
-#pragma unroll
-        for (int sl = 0; sl < S; ++sl) {
-            const int c = 4 * sl + lq;
-            a[r][sl] = (c < NN) ? Jc[((size_t)b * NC + r) * NN + (c < NN ? c : 0)] : T(0);
-        }
-    }
-    bidiag_solve_null_quad<T, NC, NN>(a, y, x, nb, lq);
+    T x[S], nb[S][NK];
+    auto aget = [&](auto rc, auto sc) -> T {
+        constexpr int r = decltype(rc)::value, sl = decltype(sc)::value;
+        const int c = 4 * sl + lq;
+        return (c < NN) ? Jc[((size_t)b * NC + r) * NN + (c < NN ? c : 0)] : T(0);
+    };
+    auto yget = [&](auto rc) -> T { return rhs ? rhs[(size_t)b * NC + decltype(rc)::value] : T(0); };
+    bidiag_solve_null_quad<T, NC, NN>(aget, yget, x, nb, lq);
 #pragma unroll
     for (int sl = 0; sl < S; ++sl) {
         const int c = 4 * sl + lq;

@@ -213,7 +213,9 @@ struct ChartState {
     T at[K];         // alpha~[r] = alpha[order of row r] for used rows, 0 for unused rows
     bool used[K];
     int cnt;
-    T anext;         // alpha[cnt]
+    T arem[K];       // action components not yet paired with a pivot row: arem[0] = alpha[cnt].  (A shifting
+                     // queue, not alpha[cnt]: the optimiser turns a select chain over alpha[k] into a dynamically
+                     // indexed load, which forces the array into scratch memory -- one global round trip per column.)
     __device__ __forceinline__ void init(const T (&alpha)[K]) {
 #pragma unroll
         for (int r = 0; r < K; ++r) {
@@ -223,7 +225,8 @@ struct ChartState {
             used[r] = false;
         }
         cnt = 0;
-        anext = alpha[0];
+#pragma unroll
+        for (int k = 0; k < K; ++k) arem[k] = alpha[k];
     }
     // examine one column (raw entries col[K]); returns its (Nc alpha) value
     __device__ __forceinline__ T examine(const T (&col)[K], const T (&alpha)[K], T tol) {
@@ -247,6 +250,7 @@ struct ChartState {
             dotv = num<T>::fma(at[r], v[r], dotv);
         }
         const bool piv = (cnt < K) && (p > tol);
+        const T anext = arem[0];
         const T result = piv ? anext : dotv;
         if (__builtin_amdgcn_ballot_w64(piv) != 0ull) {           // wave-uniform: only ~K columns ever pivot
             const T invp = piv ? num<T>::rcp(pv) : T(0);         // lanes that do not pivot apply the identity
@@ -270,10 +274,8 @@ struct ChartState {
 #pragma unroll
                 for (int c = 0; c < K; ++c) Tm[r][c] = num<T>::fma(-d[r], rk[c], Tm[r][c]);
             cnt += piv ? 1 : 0;
-            T an = alpha[K - 1];
 #pragma unroll
-            for (int k = K - 2; k >= 0; --k) an = (cnt == k) ? alpha[k] : an;
-            anext = an;
+            for (int k = 0; k + 1 < K; ++k) arem[k] = piv ? arem[k + 1] : arem[k];
         }
         return result;
     }

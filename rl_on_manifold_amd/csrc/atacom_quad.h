@@ -68,126 +68,240 @@ __device__ __forceinline__ T pick4(const T (&z)[LEN], int slot4, int lq) {
     return lq == 0 ? z0 : (lq == 1 ? z1 : (lq == 2 ? z2 : z3));
 }
 
+// ---- two-wide register vectors: on gfx950 arithmetic on them is one packed instruction (v_pk_fma_f32,
+// v_pk_mul_f32, v_pk_add_f32; op_sel broadcasts a scalar operand for free).  The solver below keeps every
+// per-row quantity as ROW PAIRS (rows 2p, 2p+1 of the same column slot in one register pair) so that all of
+// its multiply-adds are packed by construction -- the auto-vectoriser found only ~2/3 of them.  (double has no
+// packed form; the same code then simply compiles to two scalar operations.)
+template <typename T> using vec2 = T __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ vec2<T> splat2(T v) { return vec2<T>{v, v}; }
+template <typename T> __device__ __forceinline__ vec2<T> fma2(vec2<T> a, vec2<T> b, vec2<T> c) {
+    return __builtin_elementwise_fma(a, b, c);
+}
+template <typename T> __device__ __forceinline__ vec2<T> qsum2(vec2<T> v) { return vec2<T>{qsum(v.x), qsum(v.y)}; }
+// float: the two butterfly levels of 2 / 4 / 6 independent quad sums written out as v_add_f32_dpp (DPP operand
+// folded into the add).  Left to itself the compiler pairs the halves into v_pk_add_f32, which cannot take a DPP
+// operand, so every level became 2 x v_mov_dpp + v_pk_add + an s_nop for the DPP read-after-write hazard (2
+// wait states, which the assembler does not insert inside asm: the leading s_nop covers a producer issued right
+// before, the interleaving of >= 4 sums covers the second level).  Results are bitwise those of qsum().
+#define ATACOM_DPP_X1 " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define ATACOM_DPP_X2 " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void qsum_n(float& a, float& b) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0" ATACOM_DPP_X1 "v_add_f32_dpp %1, %1, %1" ATACOM_DPP_X1 "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0" ATACOM_DPP_X2 "v_add_f32_dpp %1, %1, %1" ATACOM_DPP_X2
+        : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void qsum_n(float& a, float& b, float& c, float& d) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0" ATACOM_DPP_X1 "v_add_f32_dpp %1, %1, %1" ATACOM_DPP_X1
+        "v_add_f32_dpp %2, %2, %2" ATACOM_DPP_X1 "v_add_f32_dpp %3, %3, %3" ATACOM_DPP_X1
+        "v_add_f32_dpp %0, %0, %0" ATACOM_DPP_X2 "v_add_f32_dpp %1, %1, %1" ATACOM_DPP_X2
+        "v_add_f32_dpp %2, %2, %2" ATACOM_DPP_X2 "v_add_f32_dpp %3, %3, %3" ATACOM_DPP_X2
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void qsum_n(float& a, float& b, float& c, float& d, float& e, float& f) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0" ATACOM_DPP_X1 "v_add_f32_dpp %1, %1, %1" ATACOM_DPP_X1
+        "v_add_f32_dpp %2, %2, %2" ATACOM_DPP_X1 "v_add_f32_dpp %3, %3, %3" ATACOM_DPP_X1
+        "v_add_f32_dpp %4, %4, %4" ATACOM_DPP_X1 "v_add_f32_dpp %5, %5, %5" ATACOM_DPP_X1
+        "v_add_f32_dpp %0, %0, %0" ATACOM_DPP_X2 "v_add_f32_dpp %1, %1, %1" ATACOM_DPP_X2
+        "v_add_f32_dpp %2, %2, %2" ATACOM_DPP_X2 "v_add_f32_dpp %3, %3, %3" ATACOM_DPP_X2
+        "v_add_f32_dpp %4, %4, %4" ATACOM_DPP_X2 "v_add_f32_dpp %5, %5, %5" ATACOM_DPP_X2
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+}
+__device__ __forceinline__ void qsum_n(double& a, double& b) { a = qsum(a); b = qsum(b); }
+__device__ __forceinline__ void qsum_n(double& a, double& b, double& c, double& d) {
+    a = qsum(a); b = qsum(b); c = qsum(c); d = qsum(d);
+}
+__device__ __forceinline__ void qsum_n(double& a, double& b, double& c, double& d, double& e, double& f) {
+    a = qsum(a); b = qsum(b); c = qsum(c); d = qsum(d); e = qsum(e); f = qsum(f);
+}
+// quad sums of the halves of CNT (1..3) two-wide vectors, in place
+template <int CNT, typename T>
+__device__ __forceinline__ void qsum_pairs(vec2<T> (&w)[CNT]) {
+    static_assert(CNT >= 1 && CNT <= 3, "");
+    T h[2 * CNT];
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) { h[2 * j] = w[j].x; h[2 * j + 1] = w[j].y; }
+    if constexpr (CNT == 1) qsum_n(h[0], h[1]);
+    else if constexpr (CNT == 2) qsum_n(h[0], h[1], h[2], h[3]);
+    else qsum_n(h[0], h[1], h[2], h[3], h[4], h[5]);
+#pragma unroll
+    for (int j = 0; j < CNT; ++j) w[j] = vec2<T>{h[2 * j], h[2 * j + 1]};
+}
+template <int O, typename T> __device__ __forceinline__ vec2<T> qbcast2(vec2<T> v) {
+    return vec2<T>{qbcast<O>(v.x), qbcast<O>(v.y)};
+}
+// value held by lane L (compile time) of the quad
+template <int L, typename V> __device__ __forceinline__ V qfrom(V v) { return qbcast<L>(v); }
+
 // a: M x N split by column over the quad (a[r][slot] = A[r][4*slot+lq], zeros past N); y replicated.
 // On return x[slot] and nb[slot][k] are the column-split  A^+ y  and orthonormal null basis (see
 // bidiag_solve_null in atacom_linalg.h for the algorithm and its provenance).
-template <typename T, int M, int N>
-__device__ __forceinline__ void bidiag_solve_null_quad(T (&a)[M][(N + 3) / 4], T (&y)[M], T (&x)[(N + 3) / 4],
+// The matrix and right-hand side are handed over as generators  aget(row, slot) / yget(row)  called with
+// compile-time indices (std::integral_constant), so the operands are born in their register pairs: an
+// intermediate T a[M][S] array here made the optimiser merge neighbouring stores and then fail to dissolve the
+// array, which put it in scratch / LDS (+10 us per step, measured).
+template <typename T, int M, int N, typename AF, typename YF>
+__device__ __forceinline__ void bidiag_solve_null_quad(AF&& aget, YF&& yget, T (&x)[(N + 3) / 4],
                                                        T (&nb)[(N + 3) / 4][N - M], const int lq) {
     constexpr int S = (N + 3) / 4, K = N - M;
+    constexpr int MP = (M + 1) / 2;          // row pairs (a zero row pads an odd M: it is a fixed point of every step)
+    constexpr int KP = (K + 2) / 2;          // pairs over the K null vectors + x
+    using V2 = vec2<T>;
+    V2 a2[S][MP], y2[MP];
+    static_for<0, MP>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int r0 = 2 * p, r1 = (2 * p + 1 < M) ? 2 * p + 1 : 2 * p;
+        constexpr bool two = 2 * p + 1 < M;
+        const T ya = yget(std::integral_constant<int, r0>{});
+        const T yb = two ? yget(std::integral_constant<int, r1>{}) : T(0);
+        y2[p] = V2{ya, yb};
+        static_for<0, S>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            const T va = aget(std::integral_constant<int, r0>{}, sc);
+            const T vb = two ? aget(std::integral_constant<int, r1>{}, sc) : T(0);
+            a2[s][p] = V2{va, vb};
+        });
+    });
     T d[M], e[M], taup[M];
     static_for<0, M>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         constexpr int si = i / 4, li = i % 4;      // column i lives in slot si of lane li
+        constexpr int pi = i / 2, hi = i % 2;      // row i is half hi of row pair pi
         // ---- right reflector G(i) from row i, columns > i
-        T part = (lq > li) ? a[i][si] * a[i][si] : T(0);
+        T vrow[S];
 #pragma unroll
-        for (int s = si + 1; s < S; ++s) part = num<T>::fma(a[i][s], a[i][s], part);
+        for (int s = 0; s < S; ++s) vrow[s] = a2[s][pi][hi];
+        T part = (lq > li) ? vrow[si] * vrow[si] : T(0);
+#pragma unroll
+        for (int s = si + 1; s < S; ++s) part = num<T>::fma(vrow[s], vrow[s], part);
         const T ss = qsum(part);
-        const T alpha = (li == 0) ? qbcast<0>(a[i][si]) : (li == 1) ? qbcast<1>(a[i][si])
-                      : (li == 2) ? qbcast<2>(a[i][si]) : qbcast<3>(a[i][si]);
+        const T alpha = qfrom<li>(vrow[si]);
         T beta, tp;
         const T sc = larfg_scale(alpha, ss, beta, tp);
         d[i] = beta;
         taup[i] = tp;
-        // store the FULL reflector vector in row i: 0 for c < i, 1 at c == i, v for c > i
-        a[i][si] = (lq > li) ? a[i][si] * sc : ((lq == li) ? T(1) : T(0));
+        // row i becomes the FULL reflector vector: 0 for c < i, 1 at c == i, v for c > i
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            if (s > si) a[i][s] *= sc;
-            if (s < si) a[i][s] = T(0);
+            if (s < si) vrow[s] = T(0);
+            else if (s == si) vrow[s] = (lq > li) ? vrow[s] * sc : ((lq == li) ? T(1) : T(0));
+            else vrow[s] *= sc;
+            a2[s][pi][hi] = vrow[s];
         }
         if constexpr (i < M - 1) {
+            constexpr int p0 = (i + 1) / 2;        // first row pair holding a row > i
+            // rows > i, processed in groups of (up to) 3 row pairs so that their quad sums share one DPP sequence
+            static_for<0, (MP - p0 + 2) / 3>([&](auto gc) {
+                constexpr int pa = p0 + 3 * decltype(gc)::value;
+                constexpr int CNT = (MP - pa) < 3 ? (MP - pa) : 3;
+                V2 w[CNT];
 #pragma unroll
-            for (int r = i + 1; r < M; ++r) {
-                T wp = a[r][si] * a[i][si];
+                for (int j = 0; j < CNT; ++j) {
+                    w[j] = a2[si][pa + j] * splat2(vrow[si]);
 #pragma unroll
-                for (int s = si + 1; s < S; ++s) wp = num<T>::fma(a[r][s], a[i][s], wp);
-                const T w = qsum(wp) * tp;
+                    for (int s = si + 1; s < S; ++s) w[j] = fma2(a2[s][pa + j], splat2(vrow[s]), w[j]);
+                }
+                qsum_pairs<CNT, T>(w);
 #pragma unroll
-                for (int s = si; s < S; ++s) a[r][s] = num<T>::fma(-w, a[i][s], a[r][s]);
-            }
+                for (int j = 0; j < CNT; ++j) {
+                    w[j] *= splat2(tp);
+                    if (2 * (pa + j) <= i) w[j].x = T(0);   // the pair's first row is row i itself: leave it alone
+#pragma unroll
+                    for (int s = si; s < S; ++s) a2[s][pa + j] = fma2(-w[j], splat2(vrow[s]), a2[s][pa + j]);
+                }
+            });
             // ---- left reflector H(i) from column i (slot si of lane li), rows i+1..M-1
-            T sup0 = T(0), sup1 = T(0);                  // two accumulators: the chain is on the critical path
+            // u over the pairs p0..: 0 for rows <= i, 1 at row i+1, column entries * scale below
+            V2 sq = splat2(T(0));
 #pragma unroll
-            for (int r = i + 2; r < M; ++r) {
-                if ((r - i) & 1) sup1 = num<T>::fma(a[r][si], a[r][si], sup1);
-                else sup0 = num<T>::fma(a[r][si], a[r][si], sup0);
-            }
-            const T sup = sup0 + sup1;
-            T su, alq;
-            T u[M];
-            if (li == 0) { su = qbcast<0>(sup); alq = qbcast<0>(a[i + 1][si]); }
-            else if (li == 1) { su = qbcast<1>(sup); alq = qbcast<1>(a[i + 1][si]); }
-            else if (li == 2) { su = qbcast<2>(sup); alq = qbcast<2>(a[i + 1][si]); }
-            else { su = qbcast<3>(sup); alq = qbcast<3>(a[i + 1][si]); }
+            for (int p = p0 + 1; p < MP; ++p) sq = fma2(a2[si][p], a2[si][p], sq);
+            T sup = sq.x + sq.y;
+            if constexpr (hi == 1) sup = num<T>::fma(a2[si][p0].y, a2[si][p0].y, sup);   // row i+2 shares i+1's pair
+            const T su = qfrom<li>(sup);
+            const T alq = qfrom<li>(hi == 0 ? a2[si][p0].y : a2[si][p0].x);
             T betaq, tq;
             const T scq = larfg_scale(alq, su, betaq, tq);
             e[i] = betaq;
+            V2 u2[MP];
 #pragma unroll
-            for (int r = i + 2; r < M; ++r) {
-                const T col = (li == 0) ? qbcast<0>(a[r][si]) : (li == 1) ? qbcast<1>(a[r][si])
-                            : (li == 2) ? qbcast<2>(a[r][si]) : qbcast<3>(a[r][si]);
-                u[r] = col * scq;
-            }
+            for (int p = p0; p < MP; ++p) u2[p] = qbcast2<li>(a2[si][p]) * splat2(scq);
+            if constexpr (hi == 0) u2[p0] = V2{T(0), T(1)};
+            else u2[p0].x = T(1);
 #pragma unroll
             for (int s = si; s < S; ++s) {
-                T w = a[i + 1][s], w1 = T(0);
+                V2 acc = u2[p0] * a2[s][p0];
 #pragma unroll
-                for (int r = i + 2; r < M; ++r) {
-                    if ((r - i) & 1) w1 = num<T>::fma(u[r], a[r][s], w1);
-                    else w = num<T>::fma(u[r], a[r][s], w);
-                }
-                w = (w + w1) * tq;
+                for (int p = p0 + 1; p < MP; ++p) acc = fma2(u2[p], a2[s][p], acc);
+                T w = (acc.x + acc.y) * tq;
                 if (s == si) w = (lq > li) ? w : T(0);          // columns <= i are not touched
-                a[i + 1][s] -= w;
 #pragma unroll
-                for (int r = i + 2; r < M; ++r) a[r][s] = num<T>::fma(-w, u[r], a[r][s]);
+                for (int p = p0; p < MP; ++p) a2[s][p] = fma2(splat2(-w), u2[p], a2[s][p]);
             }
             {
-                T w = y[i + 1];
+                V2 acc = u2[p0] * y2[p0];
 #pragma unroll
-                for (int r = i + 2; r < M; ++r) w = num<T>::fma(u[r], y[r], w);
-                w *= tq;
-                y[i + 1] -= w;
+                for (int p = p0 + 1; p < MP; ++p) acc = fma2(u2[p], y2[p], acc);
+                const T w = (acc.x + acc.y) * tq;
 #pragma unroll
-                for (int r = i + 2; r < M; ++r) y[r] = num<T>::fma(-w, u[r], y[r]);
+                for (int p = p0; p < MP; ++p) y2[p] = fma2(splat2(-w), u2[p], y2[p]);
             }
         }
     });
     // ---- z = B^{-1} Q^T y (replicated), then split by column
     T z[M];
-    z[0] = num<T>::div(y[0], d[0]);
+    z[0] = num<T>::div(y2[0].x, d[0]);
 #pragma unroll
-    for (int i = 1; i < M; ++i) z[i] = num<T>::div(num<T>::fma(-e[i - 1], z[i - 1], y[i]), d[i]);
+    for (int i = 1; i < M; ++i) z[i] = num<T>::div(num<T>::fma(-e[i - 1], z[i - 1], y2[i / 2][i % 2]), d[i]);
+    // [nb_0 .. nb_{K-1}, x] as pairs over the vector index
+    V2 nx[S][KP];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
-        x[s] = pick4<T, M>(z, 4 * s, lq);
 #pragma unroll
-        for (int k = 0; k < K; ++k) nb[s][k] = (4 * s + lq == M + k) ? T(1) : T(0);
+        for (int j = 0; j < KP; ++j) {
+            T h[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int k = 2 * j + t;
+                h[t] = (k < K) ? ((4 * s + lq == M + k) ? T(1) : T(0)) : ((k == K) ? pick4<T, M>(z, 4 * s, lq) : T(0));
+            }
+            nx[s][j] = V2{h[0], h[1]};
+        }
     }
-    // ---- [x | nb] <- G(1) ... G(M) [x | nb]
+    // ---- [nb | x] <- G(1) ... G(M) [nb | x]
     static_for<0, M>([&](auto kc) {
         constexpr int i = M - 1 - decltype(kc)::value;
         constexpr int si = i / 4;
-        {
-            T wp = a[i][si] * x[si];
+        T vrow[S];
 #pragma unroll
-            for (int s = si + 1; s < S; ++s) wp = num<T>::fma(a[i][s], x[s], wp);
-            const T w = qsum(wp) * taup[i];
+        for (int s = si; s < S; ++s) vrow[s] = a2[s][i / 2][i % 2];
+        static_for<0, (KP + 2) / 3>([&](auto gc) {
+            constexpr int ja = 3 * decltype(gc)::value;
+            constexpr int CNT = (KP - ja) < 3 ? (KP - ja) : 3;
+            V2 w[CNT];
 #pragma unroll
-            for (int s = si; s < S; ++s) x[s] = num<T>::fma(-w, a[i][s], x[s]);
-        }
+            for (int j = 0; j < CNT; ++j) {
+                w[j] = splat2(vrow[si]) * nx[si][ja + j];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            T wp = a[i][si] * nb[si][k];
+                for (int s = si + 1; s < S; ++s) w[j] = fma2(splat2(vrow[s]), nx[s][ja + j], w[j]);
+            }
+            qsum_pairs<CNT, T>(w);
 #pragma unroll
-            for (int s = si + 1; s < S; ++s) wp = num<T>::fma(a[i][s], nb[s][k], wp);
-            const T w = qsum(wp) * taup[i];
+            for (int j = 0; j < CNT; ++j) {
+                w[j] *= splat2(taup[i]);
 #pragma unroll
-            for (int s = si; s < S; ++s) nb[s][k] = num<T>::fma(-w, a[i][s], nb[s][k]);
-        }
+                for (int s = si; s < S; ++s) nx[s][ja + j] = fma2(-w[j], splat2(vrow[s]), nx[s][ja + j]);
+            }
+        });
     });
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        x[s] = nx[s][K / 2][K % 2];
+#pragma unroll
+        for (int k = 0; k < K; ++k) nb[s][k] = nx[s][k / 2][k % 2];
+    }
 }
 
 // Chart (rref + Nc @ alpha) on the column-split null basis.
