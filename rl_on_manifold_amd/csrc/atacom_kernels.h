@@ -287,15 +287,15 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
             y[r] = (E::MODE == 1) ? P.Kc[r] * cs : num<T>::fma(P.Kc[r], cs, psir);     // E: no drift term (:127)
         }
         if (LANES == 1 || E::MODE != 0) {
-            T a[NC][NN], x[NN], nb[NN][NN - NC], nmu[NN];
-#pragma unroll
-            for (int r = 0; r < NC; ++r) {
-#pragma unroll
-                for (int c = 0; c < NQ; ++c) a[r][c] = USE_PARK ? park[(r * NQ + c) * PARK_STRIDE] : A[r][c];
-#pragma unroll
-                for (int g = 0; g < NG; ++g) a[r][NQ + g] = (r == NF + g) ? st.s[g] : T(0);
-            }
-            bidiag_solve_null<T, NC, NN>(a, y, x, nb);              // atacom.py:127 (pinv_null)
+            T x[NN], nb[NN][NN - NC], nmu[NN];
+            auto aget = [&](auto rc, auto cc) -> T {
+                constexpr int r = decltype(rc)::value, c = decltype(cc)::value;
+                if constexpr (c < NQ) return USE_PARK ? park[(r * NQ + c) * PARK_STRIDE] : A[r][c];
+                else if constexpr (r == NF + (c - NQ)) return st.s[c - NQ];
+                else return T(0);
+            };
+            auto yget = [&](auto rc) -> T { return y[decltype(rc)::value]; };
+            bidiag_solve_null<T, NC, NN>(aget, yget, x, nb);        // atacom.py:127 (pinv_null)
             if (E::MODE == 1) {
                 // error_correction_wrapper.py:127-130: [alpha; 0] - Jc^+ (Kc c), the null basis is not used
 #pragma unroll
@@ -751,14 +751,12 @@ __global__ void __launch_bounds__(WAVE) k_nullspace(int n, const T* __restrict__
     constexpr int NC = E::NC, NN = E::NN, NK = E::NN - E::NC;     // NK here = null-space dimension
     const int b = blockIdx.x * WAVE + threadIdx.x;
     if (b >= n) return;
-    T a[NC][NN], y[NC], x[NN], nb[NN][NK];
-#pragma unroll
-    for (int r = 0; r < NC; ++r) {
-        y[r] = rhs ? rhs[(size_t)b * NC + r] : T(0);
-#pragma unroll
-        for (int c = 0; c < NN; ++c) a[r][c] = Jc[((size_t)b * NC + r) * NN + c];
-    }
-    bidiag_solve_null<T, NC, NN>(a, y, x, nb);
+    T x[NN], nb[NN][NK];
+    auto aget = [&](auto rc, auto cc) -> T {
+        return Jc[((size_t)b * NC + decltype(rc)::value) * NN + decltype(cc)::value];
+    };
+    auto yget = [&](auto rc) -> T { return rhs ? rhs[(size_t)b * NC + decltype(rc)::value] : T(0); };
+    bidiag_solve_null<T, NC, NN>(aget, yget, x, nb);
     if (xo) {
 #pragma unroll
         for (int c = 0; c < NN; ++c) xo[(size_t)b * NN + c] = x[c];

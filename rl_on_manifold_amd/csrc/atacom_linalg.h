@@ -18,6 +18,7 @@
 // is a dependent chain of rank-1 updates, not a shared-operand contraction.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace atacom {
 
@@ -79,6 +80,28 @@ template <> struct num<double> {
     static __device__ __forceinline__ double min(double a, double b) { return fmin(a, b); }
 };
 
+// compile-time loop: the body is instantiated once per index, so every array index below is a constant
+// regardless of what the loop unroller decides (the DPP intrinsics are `convergent`, which makes LLVM
+// reluctant to fully unroll the big outer loops on its own).
+template <int I, int END, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < END) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, END>(f);
+    }
+}
+
+// ---- two-wide register vectors: on gfx950 arithmetic on them is one packed instruction (v_pk_fma_f32,
+// v_pk_mul_f32, v_pk_add_f32; op_sel broadcasts a scalar operand for free).  The solver below keeps every
+// per-row quantity as ROW PAIRS (rows 2p, 2p+1 of the same column slot in one register pair) so that all of
+// its multiply-adds are packed by construction -- the auto-vectoriser found only ~2/3 of them.  (double has no
+// packed form; the same code then simply compiles to two scalar operations.)
+template <typename T> using vec2 = T __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ vec2<T> splat2(T v) { return vec2<T>{v, v}; }
+template <typename T> __device__ __forceinline__ vec2<T> fma2(vec2<T> a, vec2<T> b, vec2<T> c) {
+    return __builtin_elementwise_fma(a, b, c);
+}
+
 // LAPACK dlarfg on (alpha, x[0..L)) given ss = sum x^2: H = I - tau [1;v][1;v]^T, H [alpha;x] = [beta;0].
 // Returns the scale 1/(alpha-beta) to apply to x (0 when x == 0, i.e. H = I), writes beta and tau.
 template <typename T>
@@ -93,101 +116,140 @@ __device__ __forceinline__ T larfg_scale(T alpha, T ss, T& beta, T& tau) {
     return nz ? num<T>::rcp(den) : T(0);
 }
 
-// a: M x N (row i, col j), full row rank; y: right-hand side (length M).
-// On return  x = a^+ y  (length N)  and  nb = orthonormal null basis (N x K, K = N - M), equal to
-// scipy.linalg.svd(a, full_matrices=True)[2][M:].T up to rounding.  a and y are destroyed.
-template <typename T, int M, int N>
-__device__ __forceinline__ void bidiag_solve_null(T (&a)[M][N], T (&y)[M], T (&x)[N], T (&nb)[N][N - M]) {
+// A: M x N (row i, col j), full row rank; y: right-hand side (length M) -- both handed over as generators
+// aget(row, col) / yget(row) called with compile-time indices (std::integral_constant), so the operands are born
+// in their registers (an intermediate T a[M][N] array invites the optimiser to merge stores into it and then fail
+// to dissolve it, which lands it in scratch memory).
+// On return  x = A^+ y  (length N)  and  nb = orthonormal null basis (N x K, K = N - M), equal to
+// scipy.linalg.svd(A, full_matrices=True)[2][M:].T up to rounding.
+// Every per-row quantity is kept as ROW PAIRS (vec2: rows 2p, 2p+1 of one column) and the K null vectors + x as
+// pairs over the vector index, so all multiply-adds are packed (v_pk_fma_f32) by construction.
+template <typename T, int M, int N, typename AF, typename YF>
+__device__ __forceinline__ void bidiag_solve_null(AF&& aget, YF&& yget, T (&x)[N], T (&nb)[N][N - M]) {
     constexpr int K = N - M;
+    constexpr int MP = (M + 1) / 2;          // row pairs (a zero row pads an odd M: it is a fixed point of every step)
+    constexpr int KP = (K + 2) / 2;          // pairs over [nb_0 .. nb_{K-1}, x]
+    using V2 = vec2<T>;
+    V2 a2[MP][N], y2[MP];
+    static_for<0, MP>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int r0 = 2 * p, r1 = (2 * p + 1 < M) ? 2 * p + 1 : 2 * p;
+        constexpr bool two = 2 * p + 1 < M;
+        const T ya = yget(std::integral_constant<int, r0>{});
+        const T yb = two ? yget(std::integral_constant<int, r1>{}) : T(0);
+        y2[p] = V2{ya, yb};
+        static_for<0, N>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            const T va = aget(std::integral_constant<int, r0>{}, cc);
+            const T vb = two ? aget(std::integral_constant<int, r1>{}, cc) : T(0);
+            a2[p][c] = V2{va, vb};
+        });
+    });
     T d[M], e[M], taup[M];
-#pragma unroll
-    for (int i = 0; i < M; ++i) {
-        __builtin_amdgcn_sched_barrier(0);     // do not overlap reflector steps: keeps the live set near M*N
-        // ---- right reflector G(i): annihilate a[i][i+1..N)
+    static_for<0, M>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int pi = i / 2, hi = i % 2;      // row i is half hi of row pair pi
+        __builtin_amdgcn_sched_barrier(0);         // do not overlap reflector steps: keeps the live set near M*N
+        // ---- right reflector G(i): annihilate A[i][i+1..N); v (v[i] = 1 implicit) stays in row i
         T ss = T(0);
 #pragma unroll
-        for (int c = i + 1; c < N; ++c) ss = num<T>::fma(a[i][c], a[i][c], ss);
+        for (int c = i + 1; c < N; ++c) ss = num<T>::fma(a2[pi][c][hi], a2[pi][c][hi], ss);
         T beta, tp;
-        const T sc = larfg_scale(a[i][i], ss, beta, tp);
+        const T sc = larfg_scale(a2[pi][i][hi], ss, beta, tp);
         d[i] = beta;
         taup[i] = tp;
+        T v[N];
 #pragma unroll
-        for (int c = i + 1; c < N; ++c) a[i][c] *= sc;          // v (v[i] = 1 implicit) kept in place
-        if (i < M - 1) {
-            // apply G(i) from the right to rows i+1..M-1
+        for (int c = i + 1; c < N; ++c) { v[c] = a2[pi][c][hi] * sc; a2[pi][c][hi] = v[c]; }
+        if constexpr (i < M - 1) {
+            constexpr int p0 = (i + 1) / 2;        // first row pair holding a row > i
 #pragma unroll
-            for (int r = i + 1; r < M; ++r) {
-                T w = a[r][i];
+            for (int p = p0; p < MP; ++p) {
+                V2 w = a2[p][i];
 #pragma unroll
-                for (int c = i + 1; c < N; ++c) w = num<T>::fma(a[r][c], a[i][c], w);
-                w *= tp;
-                a[r][i] -= w;
+                for (int c = i + 1; c < N; ++c) w = fma2(a2[p][c], splat2(v[c]), w);
+                w *= splat2(tp);
+                if (2 * p <= i) w.x = T(0);        // the pair's first row is row i itself: leave it alone
+                a2[p][i] -= w;
 #pragma unroll
-                for (int c = i + 1; c < N; ++c) a[r][c] = num<T>::fma(-w, a[i][c], a[r][c]);
+                for (int c = i + 1; c < N; ++c) a2[p][c] = fma2(-w, splat2(v[c]), a2[p][c]);
             }
-            // ---- left reflector H(i): annihilate a[i+2..M)[i]
-            T su = T(0);
+            // ---- left reflector H(i): annihilate A[i+2..M)[i]; u over the pairs p0..: 0 for rows <= i, 1 at row
+            // i+1, scaled column entries below (not kept: Q is applied to y on the fly)
+            V2 sq = splat2(T(0));
 #pragma unroll
-            for (int r = i + 2; r < M; ++r) su = num<T>::fma(a[r][i], a[r][i], su);
+            for (int p = p0 + 1; p < MP; ++p) sq = fma2(a2[p][i], a2[p][i], sq);
+            T su = sq.x + sq.y;
+            if constexpr (hi == 1) su = num<T>::fma(a2[p0][i].y, a2[p0][i].y, su);     // row i+2 shares i+1's pair
             T betaq, tq;
-            const T scq = larfg_scale(a[i + 1][i], su, betaq, tq);
+            const T scq = larfg_scale(hi == 0 ? a2[p0][i].y : a2[p0][i].x, su, betaq, tq);
             e[i] = betaq;
+            V2 u2[MP];
 #pragma unroll
-            for (int r = i + 2; r < M; ++r) a[r][i] *= scq;      // u (u[i+1] = 1 implicit)
+            for (int p = p0; p < MP; ++p) u2[p] = a2[p][i] * splat2(scq);
+            if constexpr (hi == 0) u2[p0] = V2{T(0), T(1)};
+            else u2[p0].x = T(1);
 #pragma unroll
             for (int c = i + 1; c < N; ++c) {
-                T w = a[i + 1][c];
+                V2 acc = u2[p0] * a2[p0][c];
 #pragma unroll
-                for (int r = i + 2; r < M; ++r) w = num<T>::fma(a[r][i], a[r][c], w);
-                w *= tq;
-                a[i + 1][c] -= w;
+                for (int p = p0 + 1; p < MP; ++p) acc = fma2(u2[p], a2[p][c], acc);
+                const T w = (acc.x + acc.y) * tq;
 #pragma unroll
-                for (int r = i + 2; r < M; ++r) a[r][c] = num<T>::fma(-w, a[r][i], a[r][c]);
+                for (int p = p0; p < MP; ++p) a2[p][c] = fma2(splat2(-w), u2[p], a2[p][c]);
             }
             {   // the same H(i) on the right-hand side: y <- Q^T y
-                T w = y[i + 1];
+                V2 acc = u2[p0] * y2[p0];
 #pragma unroll
-                for (int r = i + 2; r < M; ++r) w = num<T>::fma(a[r][i], y[r], w);
-                w *= tq;
-                y[i + 1] -= w;
+                for (int p = p0 + 1; p < MP; ++p) acc = fma2(u2[p], y2[p], acc);
+                const T w = (acc.x + acc.y) * tq;
 #pragma unroll
-                for (int r = i + 2; r < M; ++r) y[r] = num<T>::fma(-w, a[r][i], y[r]);
+                for (int p = p0; p < MP; ++p) y2[p] = fma2(splat2(-w), u2[p], y2[p]);
             }
         }
-    }
+    });
     // ---- z = B^{-1} (Q^T y), B lower bidiagonal (d on the diagonal, e below it)
-    x[0] = num<T>::div(y[0], d[0]);
+    T z[M];
+    z[0] = num<T>::div(y2[0].x, d[0]);
 #pragma unroll
-    for (int i = 1; i < M; ++i) x[i] = num<T>::div(num<T>::fma(-e[i - 1], x[i - 1], y[i]), d[i]);
+    for (int i = 1; i < M; ++i) z[i] = num<T>::div(num<T>::fma(-e[i - 1], z[i - 1], y2[i / 2][i % 2]), d[i]);
+    V2 nx[N][KP];
 #pragma unroll
-    for (int c = M; c < N; ++c) x[c] = T(0);
+    for (int c = 0; c < N; ++c) {
 #pragma unroll
-    for (int r = 0; r < N; ++r)
+        for (int j = 0; j < KP; ++j) {
+            T h[2];
 #pragma unroll
-        for (int k = 0; k < K; ++k) nb[r][k] = (r == M + k) ? T(1) : T(0);
-    // ---- [x | nb] <- G(1) ... G(M) [x | nb]
-#pragma unroll
-    for (int i = M - 1; i >= 0; --i) {
+            for (int t = 0; t < 2; ++t) {
+                const int k = 2 * j + t;
+                h[t] = (k < K) ? ((c == M + k) ? T(1) : T(0)) : ((k == K && c < M) ? z[c < M ? c : 0] : T(0));
+            }
+            nx[c][j] = V2{h[0], h[1]};
+        }
+    }
+    // ---- [nb | x] <- G(1) ... G(M) [nb | x]
+    static_for<0, M>([&](auto kc) {
+        constexpr int i = M - 1 - decltype(kc)::value;
         __builtin_amdgcn_sched_barrier(0);
-        {
-            T w = x[i];
+        T v[N];
 #pragma unroll
-            for (int c = i + 1; c < N; ++c) w = num<T>::fma(a[i][c], x[c], w);
-            w *= taup[i];
-            x[i] -= w;
+        for (int c = i + 1; c < N; ++c) v[c] = a2[i / 2][c][i % 2];
 #pragma unroll
-            for (int c = i + 1; c < N; ++c) x[c] = num<T>::fma(-w, a[i][c], x[c]);
+        for (int j = 0; j < KP; ++j) {
+            V2 w = nx[i][j];
+#pragma unroll
+            for (int c = i + 1; c < N; ++c) w = fma2(splat2(v[c]), nx[c][j], w);
+            w *= splat2(taup[i]);
+            nx[i][j] -= w;
+#pragma unroll
+            for (int c = i + 1; c < N; ++c) nx[c][j] = fma2(-w, splat2(v[c]), nx[c][j]);
         }
+    });
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            T w = nb[i][k];
+    for (int c = 0; c < N; ++c) {
+        x[c] = nx[c][K / 2][K % 2];
 #pragma unroll
-            for (int c = i + 1; c < N; ++c) w = num<T>::fma(a[i][c], nb[c][k], w);
-            w *= taup[i];
-            nb[i][k] -= w;
-#pragma unroll
-            for (int c = i + 1; c < N; ++c) nb[c][k] = num<T>::fma(-w, a[i][c], nb[c][k]);
-        }
+        for (int k = 0; k < K; ++k) nb[c][k] = nx[c][k / 2][k % 2];
     }
 }
 

@@ -17,21 +17,9 @@
 // The arithmetic is the same Householder bidiagonalisation / rref chart as atacom_linalg.h (which remains
 // the one-lane-per-env reference implementation); only the summation order inside dot products differs.
 #pragma once
-#include <type_traits>
 #include "atacom_linalg.h"
 
 namespace atacom {
-
-// compile-time loop: the body is instantiated once per index, so every array index below is a constant
-// regardless of what the loop unroller decides (the DPP intrinsics are `convergent`, which makes LLVM
-// reluctant to fully unroll the big outer loops on its own).
-template <int I, int END, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < END) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, END>(f);
-    }
-}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -68,16 +56,7 @@ __device__ __forceinline__ T pick4(const T (&z)[LEN], int slot4, int lq) {
     return lq == 0 ? z0 : (lq == 1 ? z1 : (lq == 2 ? z2 : z3));
 }
 
-// ---- two-wide register vectors: on gfx950 arithmetic on them is one packed instruction (v_pk_fma_f32,
-// v_pk_mul_f32, v_pk_add_f32; op_sel broadcasts a scalar operand for free).  The solver below keeps every
-// per-row quantity as ROW PAIRS (rows 2p, 2p+1 of the same column slot in one register pair) so that all of
-// its multiply-adds are packed by construction -- the auto-vectoriser found only ~2/3 of them.  (double has no
-// packed form; the same code then simply compiles to two scalar operations.)
-template <typename T> using vec2 = T __attribute__((ext_vector_type(2)));
-template <typename T> __device__ __forceinline__ vec2<T> splat2(T v) { return vec2<T>{v, v}; }
-template <typename T> __device__ __forceinline__ vec2<T> fma2(vec2<T> a, vec2<T> b, vec2<T> c) {
-    return __builtin_elementwise_fma(a, b, c);
-}
+// ---- quad reductions / broadcasts of two-wide vectors (vec2, splat2, fma2: atacom_linalg.h)
 template <typename T> __device__ __forceinline__ vec2<T> qsum2(vec2<T> v) { return vec2<T>{qsum(v.x), qsum(v.y)}; }
 // float: the two butterfly levels of 2 / 4 / 6 independent quad sums written out as v_add_f32_dpp (DPP operand
 // folded into the add).  Left to itself the compiler pairs the halves into v_pk_add_f32, which cannot take a DPP
