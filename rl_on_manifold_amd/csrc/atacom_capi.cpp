@@ -41,13 +41,13 @@ const atacom::EnvOps* get_ops(int env_id, int dtype) {
 constexpr int kStatBlocks = 256;
 
 // kernel mapping policy for lanes_per_env = 0, from measurements on MI355X (profiles/r01_lanes_vs_batch.md):
-// the quad mapping has ~0.56x the instructions per wave but 4x the waves, so it wins while the batch cannot
-// fill the 1024 SIMDs with one-env-per-lane waves, and loses once it can.
+// the quad mapping has ~0.7x the instructions per wave but 4x the waves, so it wins while its waves still find
+// a SIMD each (16384 envs = 1024 waves) and loses beyond: a second wave on a SIMD simply doubles the time.
 int pick_lanes(const atacom_config& c) {
     if (c.lanes_per_env == 1 || c.lanes_per_env == 4) return c.lanes_per_env;
     if (c.dtype == ATACOM_F64) return 1;
-    if (c.env_id == ATACOM_ENV_IIWA) return c.batch <= 16384 ? 4 : 1;      // 58 vs 79 us @8192; 113 vs 102 us @24576
-    if (c.env_id == ATACOM_ENV_PLANAR) return (c.batch >= 2048 && c.batch <= 40960) ? 4 : 1;   // 20.5 vs 25 us @8192
+    if (c.env_id == ATACOM_ENV_IIWA) return c.batch <= 16384 ? 4 : 1;      // 38 vs 52 us @8192; 73 vs 54 us @24576
+    if (c.env_id == ATACOM_ENV_PLANAR) return c.batch <= 16384 ? 4 : 1;    // 14.4 vs 14.7 us @8192; 22 vs 15.5 us @24576
     return 1;                                                              // circle: launch-bound either way
 }
 

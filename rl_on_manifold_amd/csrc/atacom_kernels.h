@@ -177,10 +177,7 @@ __device__ __forceinline__ void reset_env(const Params<T>& P, const T* __restric
 // (and bitwise identically) by the four lanes; `lq` is the lane's index in its quad.
 template <typename T, typename E, int LANES, bool HOLD>
 __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st, const T (&act)[E::NK],
-                                         StepOut<T>& out, const int lq, T* __restrict__ park) {
-    // `park` (lane mapping, iiwa only): this lane's column of an LDS array [value][lane].  The 96 step-constant values
-    // K J, psi, c0 are parked there between sub-steps instead of occupying VGPRs next to the 12 x 17 working matrix
-    // -- otherwise the compiler spills to scratch and the wave spends ~30 % of its time waiting on it (PMC).
+                                         StepOut<T>& out, const int lq) {
     constexpr int NQ = E::NQ, NF = E::NF, NG = E::NG, NC = E::NC, NN = E::NN, NK = E::NK;
     T alpha[NK];
     T anorm2 = T(0);
@@ -219,8 +216,6 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
     T qc[NQ], dqc[NQ];          // what the controller sees (held over the sub-steps when hold_q)
     T m0x = T(0), m0y = T(0);   // mallet position at the start of the env step
     T A[NC][NQ], psi[NC], c0[NC];
-    constexpr bool USE_PARK = (LANES == 1) && (E::ID == 2) && (E::MODE == 0);
-    constexpr int PARK_STRIDE = WAVE;
     constexpr int SQ = (NN + 3) / 4;
     T Aq[NC][SQ];              // LANES == 4: this lane's columns of [K J | 0]
     auto prepare = [&](int sub) {
@@ -247,15 +242,6 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 psi[r] = num<T>::fma(P.K[r], bst[r], jdq);      // constraints.py:42-43
                 c0[r] = num<T>::fma(P.K[r], jdq, fun[r]);       // constraints.py:33-37
             }
-            if (USE_PARK) {
-#pragma unroll
-                for (int r = 0; r < NC; ++r) {
-#pragma unroll
-                    for (int i = 0; i < NQ; ++i) park[(r * NQ + i) * PARK_STRIDE] = A[r][i];
-                    park[(NC * NQ + r) * PARK_STRIDE] = psi[r];
-                    park[(NC * NQ + NC + r) * PARK_STRIDE] = c0[r];
-                }
-            }
             if (LANES == 4) {
 #pragma unroll
                 for (int r = 0; r < NC; ++r)
@@ -281,16 +267,14 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
 #pragma unroll
         for (int r = 0; r < NC; ++r) {
             const T sv = (r >= NF) ? st.s[r >= NF ? r - NF : 0] : T(0);
-            const T c0r = USE_PARK ? park[(NC * NQ + NC + r) * PARK_STRIDE] : c0[r];
-            const T psir = USE_PARK ? park[(NC * NQ + r) * PARK_STRIDE] : psi[r];
-            const T cs = num<T>::fma(T(0.5) * sv, sv, c0r);         // c = fun + K J dq (+ s^2 / 2 on g rows)
-            y[r] = (E::MODE == 1) ? P.Kc[r] * cs : num<T>::fma(P.Kc[r], cs, psir);     // E: no drift term (:127)
+            const T cs = num<T>::fma(T(0.5) * sv, sv, c0[r]);         // c = fun + K J dq (+ s^2 / 2 on g rows)
+            y[r] = (E::MODE == 1) ? P.Kc[r] * cs : num<T>::fma(P.Kc[r], cs, psi[r]);     // E: no drift term (:127)
         }
         if (LANES == 1 || E::MODE != 0) {
             T x[NN], nb[NN][NN - NC], nmu[NN];
             auto aget = [&](auto rc, auto cc) -> T {
                 constexpr int r = decltype(rc)::value, c = decltype(cc)::value;
-                if constexpr (c < NQ) return USE_PARK ? park[(r * NQ + c) * PARK_STRIDE] : A[r][c];
+                if constexpr (c < NQ) return A[r][c];
                 else if constexpr (r == NF + (c - NQ)) return st.s[c - NQ];
                 else return T(0);
             };
@@ -475,8 +459,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
 #pragma unroll
     for (int k = 0; k < E::NK; ++k) act[k] = action[(size_t)b * E::NK + k];
     StepOut<T> out;
-    extern __shared__ __attribute__((aligned(16))) char smem_step[];
-    env_step<T, E, LANES, HOLD>(P, st, act, out, lq, reinterpret_cast<T*>(smem_step) + threadIdx.x);
+    env_step<T, E, LANES, HOLD>(P, st, act, out, lq);
     if (lq != 0) return;                       // the four lanes hold identical results; lane 0 writes
     write_obs<T, E>(P, st, obs + (size_t)b * E::OBS);
     reward[b] = out.reward;
@@ -504,8 +487,6 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
     if (b >= B) return;
     EnvState<T, E> st;
     load_state<T, E>(f, ip, B, b, st);
-    extern __shared__ __attribute__((aligned(16))) char smem_roll[];
-    T* park = reinterpret_cast<T*>(smem_roll) + threadIdx.x;
     T ssum = T(0), scmax = f[L::SCMAX * (size_t)B + b], sdq = f[L::SDQMAX * (size_t)B + b];
 #pragma unroll 1
     for (int t = 0; t < n_steps; ++t) {
@@ -515,7 +496,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
 #pragma unroll
         for (int k = 0; k < E::NK; ++k) act[k] = actions[row * E::NK + k];
         StepOut<T> out;
-        env_step<T, E, LANES, HOLD>(P, st, act, out, lq, park);
+        env_step<T, E, LANES, HOLD>(P, st, act, out, lq);
         if (lq == 0) {
             if (next_obs) write_obs<T, E>(P, st, next_obs + row * E::OBS);
             reward[row] = out.reward;
@@ -547,7 +528,6 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P,
     using L = Planes<E>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* lds = reinterpret_cast<T*>(smem);
-    T* park = lds + ((2 * MlpLds<E::OBS, H, E::NK>::TOTAL + 3) / 4) * 4 + threadIdx.x;
     mlp_stage<T, E::OBS, H, E::NK>(net, lds, threadIdx.x, BLOCK<LANES>);
     const int B = P.batch;
     const int gt = blockIdx.x * BLOCK<LANES> + threadIdx.x;
@@ -588,7 +568,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P,
             for (int k = 0; k < E::NK; ++k) actions_out[row * E::NK + k] = act[k];
         }
         StepOut<T> out;
-        env_step<T, E, LANES, HOLD>(P, st, act, out, lq, park);
+        env_step<T, E, LANES, HOLD>(P, st, act, out, lq);
         if (lq == 0) {
             if (next_obs) write_obs<T, E>(P, st, next_obs + row * E::OBS);
             reward[row] = out.reward;

@@ -36,13 +36,6 @@ static Params<T> make_params(const atacom_config& c) {
 
 static inline int nblk(int n, int per) { return (n + per - 1) / per; }
 
-// dynamic LDS of the step / rollout kernels: the lane mapping of the iiwa env parks its 96 step-constant values
-// per lane in LDS (env_step's `park`), everything else needs none
-template <typename T, typename E, int LANES>
-static constexpr size_t park_bytes() {
-    return (LANES == 1 && E::ID == 2 && E::MODE == 0) ? sizeof(T) * (size_t)(E::NC * E::NQ + 2 * E::NC) * WAVE : 0;
-}
-
 template <typename T, typename E>
 struct Ops {
     using L = Planes<E>;
@@ -51,7 +44,7 @@ struct Ops {
     static void launch_step(const atacom_config& c, void* f, int* ip, const void* act, void* obs, void* rew,
                             uint8_t* ab, uint8_t* last, hipStream_t s) {
         hipLaunchKernelGGL((k_step<T, E, LANES, HOLD>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)), dim3(BLOCK<LANES>),
-                           (park_bytes<T, E, LANES>()), s,
+                           0, s,
                            make_params<T>(c), (T*)f, ip, (const T*)act, (T*)obs, (T*)rew, ab, last);
     }
     static void step(const atacom_config& c, int lanes, void* f, int* ip, const void* act, void* obs, void* rew,
@@ -68,7 +61,7 @@ struct Ops {
     static void launch_rollout(const atacom_config& c, int n_steps, void* f, int* ip, const void* acts, void* obs,
                                void* nobs, void* rew, uint8_t* ab, uint8_t* last, hipStream_t s) {
         hipLaunchKernelGGL((k_rollout<T, E, LANES, HOLD>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)), dim3(BLOCK<LANES>),
-                           (park_bytes<T, E, LANES>()), s,
+                           0, s,
                            make_params<T>(c), n_steps, (T*)f, ip, (const T*)acts, (T*)obs, (T*)nobs, (T*)rew, ab, last);
     }
     static void rollout(const atacom_config& c, int lanes, int n_steps, void* f, int* ip, const void* acts, void* obs,
@@ -86,7 +79,7 @@ struct Ops {
                            const void* noise, void* obs, void* nobs, void* acts, void* rew, uint8_t* ab,
                            uint8_t* last, hipStream_t s) {
         constexpr int H = 64;
-        const size_t lds_bytes = sizeof(T) * (((2 * MlpLds<E::OBS, H, E::NK>::TOTAL + 3) / 4) * 4) + park_bytes<T, E, LANES>();
+        const size_t lds_bytes = sizeof(T) * (((2 * MlpLds<E::OBS, H, E::NK>::TOTAL + 3) / 4) * 4);
         hipLaunchKernelGGL((k_rollout_mlp<T, E, LANES, HOLD, H>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)),
                            dim3(BLOCK<LANES>),
                            lds_bytes, s, make_params<T>(c), a, n_steps, (T*)f, ip, (const T*)noise, (T*)obs, (T*)nobs,
