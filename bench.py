@@ -63,6 +63,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--env', default='iiwa')
     ap.add_argument('--batch', type=int, default=8192)
+    ap.add_argument('--lanes', type=int, default=0, help='kernel mapping: 0 = library policy, 1 = env per lane, 4 = env per quad')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     args = ap.parse_args()
@@ -87,7 +88,7 @@ def main():
     red_dev = dev if backend == 'nccl' else torch.device('cpu')
 
     B, K, W = args.batch, args.steps, args.warmup
-    env = BatchedAtacomEnv(args.env, B, device=dev, dtype=torch.float32, auto_reset=True)
+    env = BatchedAtacomEnv(args.env, B, device=dev, dtype=torch.float32, auto_reset=True, lanes_per_env=args.lanes)
     k, D = env.dims['null'], env.obs_dim
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -194,7 +195,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': {'iiwa': 'IiwaAirHockey env 7H', 'planar': 'PlanarAirHockey env H',
                                     'circle': 'CircularMotion env A'}[args.env] + ', batch %d per GPU' % B,
-                       'batch_per_gpu': B, 'global_batch': B * world, 'substeps': int(env.cfg.substeps),
+                       'batch_per_gpu': B, 'global_batch': B * world, 'lanes_per_env_requested': int(env.cfg.lanes_per_env), 'substeps': int(env.cfg.substeps),
                        'horizon': int(env.cfg.horizon), 'path': 'atacom_step (1 launch / step) via C ABI',
                        'parallelism': 'env-shard x%d, no data-path collective' % world},
             'max_abs_c': c_max, 'c_avg': c_avg, 'c_dq_max': c_dq_max,

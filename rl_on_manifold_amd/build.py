@@ -18,6 +18,9 @@ ARCH = 'gfx950'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + \
     os.environ.get('ATACOM_HIPCC_FLAGS', '').split()
 UNITS = ['atacom_circle.hip', 'atacom_planar.hip', 'atacom_iiwa.hip', 'atacom_capi.cpp']
+# per-unit scheduler choice, measured on MI355X (profiles/r01_lanes_vs_batch.md): the planar kernels have register
+# headroom and gain ~5 % from the ILP-first strategy; the iiwa quad kernel sits at the 256-VGPR limit and loses 8 %.
+UNIT_FLAGS = {'atacom_planar.hip': ['-mllvm', '-amdgpu-sched-strategy=max-ilp']}
 
 
 def _sources():
@@ -36,7 +39,7 @@ def needs_build():
 def _compile(unit):
     src = os.path.join(CSRC, unit)
     obj = os.path.join(CSRC, os.path.splitext(unit)[0] + os.environ.get('ATACOM_OBJ_TAG', '') + '.o')
-    cmd = [HIPCC] + FLAGS + (['-x', 'hip'] if unit.endswith('.cpp') else []) + ['-c', src, '-o', obj]
+    cmd = [HIPCC] + FLAGS + UNIT_FLAGS.get(unit, []) + (['-x', 'hip'] if unit.endswith('.cpp') else []) + ['-c', src, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (unit, ' '.join(cmd), r.stderr[-4000:]))
