@@ -10,11 +10,14 @@ engine: collection = ONE kernel launch per iteration (policy MLP + exploration n
     python examples/ppo_air_hockey.py --env planar --iters 60
 """
 import argparse
+import os
+import sys
 import time
 
 import torch
 import torch.nn as nn
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # run from anywhere in the checkout
 from rl_on_manifold_amd import BatchedAtacomEnv, MlpPolicy
 
 
