@@ -243,14 +243,22 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 c0[r] = num<T>::fma(P.K[r], jdq, fun[r]);       // constraints.py:33-37
             }
             if (LANES == 4) {
+                // this lane's columns of K J: a one-hot blend over the quad (exact: the mask is 0 / 1 and the entries
+                // carry no -0 after the fma above).  Written as arithmetic on purpose -- a `lq == l ? ... : ...`
+                // select chain over all rows is turned into a 4-way divergent switch by the optimiser (measured:
+                // 350 instructions for this block).
+                T oh[4];
+#pragma unroll
+                for (int l = 0; l < 4; ++l) oh[l] = (lq == l) ? T(1) : T(0);
 #pragma unroll
                 for (int r = 0; r < NC; ++r)
 #pragma unroll
                     for (int sl = 0; sl < SQ; ++sl) {
-                        T cand[4];
+                        T v = T(0);
 #pragma unroll
-                        for (int l = 0; l < 4; ++l) cand[l] = (4 * sl + l < NQ) ? A[r][4 * sl + l < NQ ? 4 * sl + l : 0] : T(0);
-                        Aq[r][sl] = lq == 0 ? cand[0] : (lq == 1 ? cand[1] : (lq == 2 ? cand[2] : cand[3]));
+                        for (int l = 0; l < 4; ++l)
+                            if (4 * sl + l < NQ) v = num<T>::fma(oh[l], A[r][4 * sl + l < NQ ? 4 * sl + l : 0], v);
+                        Aq[r][sl] = v;
                     }
             }
     };

@@ -46,14 +46,15 @@ __device__ __forceinline__ T qsum(T v) {
     const T s1 = v + dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
     return s1 + dpp_mov<0x4E>(s1);         // quad_perm [2,3,0,1]
 }
-// element 4*slot + lq of a replicated compile-time-indexed array (0 past its end)
+// element 4*slot + lq of a replicated compile-time-indexed array (0 past its end), as a one-hot blend over the
+// quad (exact for finite inputs; a select chain on lq tends to be lowered to a divergent switch)
 template <typename T, int LEN>
 __device__ __forceinline__ T pick4(const T (&z)[LEN], int slot4, int lq) {
-    const T z0 = slot4 + 0 < LEN ? z[slot4 + 0 < LEN ? slot4 + 0 : 0] : T(0);
-    const T z1 = slot4 + 1 < LEN ? z[slot4 + 1 < LEN ? slot4 + 1 : 0] : T(0);
-    const T z2 = slot4 + 2 < LEN ? z[slot4 + 2 < LEN ? slot4 + 2 : 0] : T(0);
-    const T z3 = slot4 + 3 < LEN ? z[slot4 + 3 < LEN ? slot4 + 3 : 0] : T(0);
-    return lq == 0 ? z0 : (lq == 1 ? z1 : (lq == 2 ? z2 : z3));
+    T v = T(0);
+#pragma unroll
+    for (int l = 0; l < 4; ++l)
+        if (slot4 + l < LEN) v = num<T>::fma((lq == l) ? T(1) : T(0), z[slot4 + l < LEN ? slot4 + l : 0], v);
+    return v;
 }
 
 // ---- quad reductions / broadcasts of two-wide vectors (vec2, splat2, fma2: atacom_linalg.h)
