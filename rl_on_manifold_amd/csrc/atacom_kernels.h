@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P,
         for (int k = 0; k < E::NK; ++k) {
             const T eps = noise ? noise[row * E::NK + k] : T(0);
             act[k] = num<T>::fma(sig[k], eps, act[k]);
-            if (net.squash) act[k] = tanh(act[k]);
+            if (net.squash) act[k] = num<T>::tanh(act[k]);
         }
         if (lq == 0) {
 #pragma unroll

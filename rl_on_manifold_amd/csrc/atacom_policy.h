@@ -11,9 +11,10 @@
 // Mapping: weights are staged once per workgroup into LDS (26 KB in f32, rows padded so that the four lanes of
 // a quad hit different banks).  With 4 lanes per env the hidden units are interleaved over the quad (unit j ->
 // lane j % 4): layer 1 and 2 cost 1/4 each per lane, the hidden vector is re-assembled with DPP broadcasts, the
-// output layer is a partial dot product + quad sum.  This is ~1.8 k instructions per env step (+8 %).
+// output layer is a partial dot product + quad sum.  Weights leave LDS as ds_read_b128 and meet the (paired)
+// activations as v_pk_fma_f32: ~0.75 k packed FMAs + 0.37 k LDS reads per network and env step.
 // MFMA was considered and rejected here: per wave the GEMM is only 16 x 64 x 64 and the A operand would have to
-// be re-laid-out from the quad-replicated observation through LDS on every step; the VALU form is <10 % of the
+// be re-laid-out from the quad-replicated observation through LDS on every step; the VALU form is ~10 % of the
 // step and needs no layout change.
 #pragma once
 #include "atacom_quad.h"
@@ -75,7 +76,53 @@ __device__ __forceinline__ void mlp_stage(const MlpArgs<T>& net, T* lds, int tid
 
 template <typename T>
 __device__ __forceinline__ T mlp_act(T v, int activation) {
-    return activation == 0 ? num<T>::max(v, T(0)) : tanh(v);
+    return activation == 0 ? num<T>::max(v, T(0)) : num<T>::tanh(v);
+}
+
+template <typename T> using vec4 = T __attribute__((ext_vector_type(4)));
+
+// one dense layer for this lane's units: out[m] = act(b[j] + W[j][:] . in),  j = LANES * m + lq.
+// The input is replicated in the quad and held as pairs; a weight row comes out of LDS four floats per ds_read_b128
+// (rows are zero-padded to a multiple of 4) and meets the input as two packed FMAs -- 2 MACs per issue slot, the
+// two halves of the accumulator double as the two summation chains.
+template <typename T, int NIN4, int U, int LANES>
+__device__ __forceinline__ void mlp_dense(const T* __restrict__ w, int stride, const T* __restrict__ bias,
+                                          const vec2<T> (&in2)[2 * NIN4], int activation, int lq, T (&out)[U]) {
+    using V2 = vec2<T>;
+    using V4 = vec4<T>;
+#pragma unroll
+    for (int m = 0; m < U; ++m) {
+        const int j = LANES * m + lq;
+        const V4* row = reinterpret_cast<const V4*>(w + j * stride);
+        V2 acc0 = V2{bias[j], T(0)}, acc1 = splat2(T(0));      // two independent packed chains = four partial sums
+#pragma unroll
+        for (int q = 0; q < NIN4; ++q) {
+            const V4 r = row[q];
+            acc0 = fma2(V2{r.x, r.y}, in2[2 * q], acc0);
+            acc1 = fma2(V2{r.z, r.w}, in2[2 * q + 1], acc1);
+        }
+        const V2 acc = acc0 + acc1;
+        out[m] = mlp_act(acc.x + acc.y, activation);
+        // one unit's weight row in flight at a time: left alone the scheduler hoists every ds_read of the layer to
+        // the top and spills the rows to scratch
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// this lane's hidden units -> the full hidden vector, replicated in the quad, as pairs
+template <typename T, int H, int LANES>
+__device__ __forceinline__ void mlp_gather(const T (&h)[H / LANES], vec2<T> (&full)[H / 2]) {
+    using V2 = vec2<T>;
+    if constexpr (LANES == 4) {
+#pragma unroll
+        for (int m = 0; m < H / 4; ++m) {
+            full[2 * m] = V2{qbcast<0>(h[m]), qbcast<1>(h[m])};
+            full[2 * m + 1] = V2{qbcast<2>(h[m]), qbcast<3>(h[m])};
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < H / 2; ++m) full[m] = V2{h[2 * m], h[2 * m + 1]};
+    }
 }
 
 // mean action of the policy for one env: x = normalised observation (replicated in the quad)
@@ -83,51 +130,46 @@ template <typename T, int D, int H, int NK, int LANES>
 __device__ __forceinline__ void mlp_forward(const T* __restrict__ lds, const T* __restrict__ lds_norm,
                                             const T (&obs)[D], int activation, int lq, T (&mean)[NK]) {
     using L = MlpLds<D, H, NK>;
-    constexpr int U = H / LANES;
-    T x[D];
+    using V2 = vec2<T>;
+    using V4 = vec4<T>;
+    static_assert(H % 4 == 0 && H % LANES == 0 && NK <= 8, "");
+    constexpr int U = H / LANES, D4 = (D + 3) / 4;
+    V2 x2[2 * D4];
 #pragma unroll
-    for (int i = 0; i < D; ++i) x[i] = (obs[i] - lds_norm[L::SHIFT + i]) * lds_norm[L::SCALE + i];
-    T h1[U];
+    for (int i = 0; i < 2 * D4; ++i) {
+        T h[2];
 #pragma unroll
-    for (int m = 0; m < U; ++m) {
-        const int j = LANES * m + lq;
-        const T* row = lds + L::W1 + j * L::S1;
-        T acc = lds[L::B1 + j];
-#pragma unroll
-        for (int i = 0; i < D; ++i) acc = num<T>::fma(row[i], x[i], acc);
-        h1[m] = mlp_act(acc, activation);
-        __builtin_amdgcn_sched_barrier(0);       // keep at most one unit's weights in flight (register pressure)
-    }
-    T f1[H];
-#pragma unroll
-    for (int m = 0; m < U; ++m) {
-        if (LANES == 4) {
-            f1[4 * m + 0] = qbcast<0>(h1[m]); f1[4 * m + 1] = qbcast<1>(h1[m]);
-            f1[4 * m + 2] = qbcast<2>(h1[m]); f1[4 * m + 3] = qbcast<3>(h1[m]);
-        } else {
-            f1[m] = h1[m];
+        for (int t = 0; t < 2; ++t) {
+            const int c = 2 * i + t;
+            h[t] = (c < D) ? (obs[c < D ? c : 0] - lds_norm[L::SHIFT + (c < D ? c : 0)]) * lds_norm[L::SCALE + (c < D ? c : 0)]
+                           : T(0);
         }
+        x2[i] = V2{h[0], h[1]};
     }
-    T h2[U];
+    T h1[U], h2[U];
+    V2 f1[H / 2], f2[H / 2];
+    mlp_dense<T, D4, U, LANES>(lds + L::W1, L::S1, lds + L::B1, x2, activation, lq, h1);
+    mlp_gather<T, H, LANES>(h1, f1);
+    mlp_dense<T, H / 4, U, LANES>(lds + L::W2, L::S2, lds + L::B2, f1, activation, lq, h2);
+    // output layer: W3 is stored transposed, [unit][8]; this lane's units contribute partial sums over the quad
+    V2 part[4] = {splat2(T(0)), splat2(T(0)), splat2(T(0)), splat2(T(0))};
 #pragma unroll
     for (int m = 0; m < U; ++m) {
-        const int j = LANES * m + lq;
-        const T* row = lds + L::W2 + j * L::S2;
-        T acc = lds[L::B2 + j];
-#pragma unroll
-        for (int i = 0; i < H; ++i) {
-            acc = num<T>::fma(row[i], f1[i], acc);
-            if ((i & 15) == 15) __builtin_amdgcn_sched_barrier(0);
-        }
-        h2[m] = mlp_act(acc, activation);
+        const V4* row = reinterpret_cast<const V4*>(lds + L::W3T + (LANES * m + lq) * L::S3);
+        const V4 r0 = row[0], r1 = row[1];
+        const V2 hm = splat2(h2[m]);
+        part[0] = fma2(V2{r0.x, r0.y}, hm, part[0]);
+        if (NK > 2) part[1] = fma2(V2{r0.z, r0.w}, hm, part[1]);
+        if (NK > 4) part[2] = fma2(V2{r1.x, r1.y}, hm, part[2]);
+        if (NK > 6) part[3] = fma2(V2{r1.z, r1.w}, hm, part[3]);
+        if ((m & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int o = 0; o < NK; ++o) {
-        T part = T(0);
-#pragma unroll
-        for (int m = 0; m < U; ++m) part = num<T>::fma(lds[L::W3T + (LANES * m + lq) * L::S3 + o], h2[m], part);
-        mean[o] = lds[L::B3 + o] + (LANES == 4 ? qsum(part) : part);
+        const T p = part[o / 2][o % 2];
+        mean[o] = lds[L::B3 + o] + (LANES == 4 ? qsum(p) : p);
     }
+    (void)f2;
 }
 
 }  // namespace atacom
