@@ -124,7 +124,7 @@ template <int L, typename V> __device__ __forceinline__ V qfrom(V v) { return qb
 // intermediate T a[M][S] array here made the optimiser merge neighbouring stores and then fail to dissolve the
 // array, which put it in scratch / LDS (+10 us per step, measured).
 template <typename T, int M, int N, typename AF, typename YF>
-__device__ __forceinline__ void bidiag_solve_null_quad(AF&& aget, YF&& yget, T (&x)[(N + 3) / 4],
+__device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, YF&& yget, T (&x)[(N + 3) / 4],
                                                        T (&nb)[(N + 3) / 4][N - M], const int lq) {
     constexpr int S = (N + 3) / 4, K = N - M;
     constexpr int MP = (M + 1) / 2;          // row pairs (a zero row pads an odd M: it is a fixed point of every step)
@@ -299,34 +299,29 @@ __device__ __forceinline__ void bidiag_solve_null_quad(AF&& aget, YF&& yget, T (
 //   * the skip-zeroing is never materialised: eliminations are gated to columns >= the pivot column, so a
 //     skipped column is frozen from the moment it is passed, and the final contraction only takes, for
 //     column c, the rows that were already pivot rows when c was passed (jrow[r] <= c);
-//   * rows are not physically swapped: row r remembers the column jrow[r] at which it became a pivot row and
-//     the action component ar[r] = alpha[round] that the reference's row order pairs it with;
-//   * the pivot-row scaling and the elimination are one fused update  row_r -= g_r * (row_p / pivot)  with
-//     g_p = pivot - 1, which leaves no per-element select in the K x S inner loop.
+//   * rows ARE swapped like the reference's (pivot row <-> row t in round t), so "not yet a pivot row" is simply
+//     r >= t, a compile-time range: no used[] masks in the column scan or the arg-max, alpha[r] pairs with row r,
+//     and np.argmax's first-maximum tie-break is reproduced in the reference's own row order.
 // out[slot] = (Nc @ alpha)[4*slot + lq].
 template <typename T, int N, int K>
-__device__ __forceinline__ void rref_apply_quad(T (&nb)[(N + 3) / 4][K], const T (&alpha)[K], T tol,
+__device__ __forceinline__ void rref_apply_quad_inl(T (&nb)[(N + 3) / 4][K], const T (&alpha)[K], T tol,
                                                 T (&out)[(N + 3) / 4], const int lq) {
     constexpr int S = (N + 3) / 4;
     constexpr int BIG = 1 << 20;
     int col[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) col[s] = 4 * s + lq;
-    bool used[K];
-    int jrow[K];
-    T ar[K];
-#pragma unroll
-    for (int r = 0; r < K; ++r) { used[r] = false; jrow[r] = BIG; ar[r] = T(0); }
+    int jrow[K];                       // column at which row r became a pivot row (BIG: never)
     int j0 = 0;
     static_for<0, K>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        // ---- next pivot column: first column >= j0 with max |entry| over the unused rows > tol
+        constexpr int t = decltype(tc)::value;          // round t: rows < t are pivot rows, rows >= t are not
+        // ---- next pivot column: first column >= j0 with max |entry| over the rows >= t above tol
         int cand = BIG;
 #pragma unroll
         for (int s = S - 1; s >= 0; --s) {
-            T cm = T(0);
+            T cm = num<T>::abs(nb[s][t]);
 #pragma unroll
-            for (int r = 0; r < K; ++r) cm = num<T>::max(cm, used[r] ? T(0) : num<T>::abs(nb[s][r]));
+            for (int r = t + 1; r < K; ++r) cm = num<T>::max(cm, num<T>::abs(nb[s][r]));
             const bool e = (cm > tol) && (col[s] >= j0);
             cand = e ? col[s] : cand;
         }
@@ -345,52 +340,86 @@ __device__ __forceinline__ void rref_apply_quad(T (&nb)[(N + 3) / 4][K], const T
             for (int s = 1; s < S; ++s) v = num<T>::fma(w[s], nb[s][r], v);
             f[r] = qsum(v);
         }
-        // ---- pivot row: first arg-max of |f| over the unused rows
+        // ---- pivot row: first arg-max of |f| over rows t..K-1 (np.argmax semantics in the reference's row order)
         T p = T(-1);
+        int kk = t;
 #pragma unroll
-        for (int r = 0; r < K; ++r) p = num<T>::max(p, used[r] ? T(-1) : num<T>::abs(f[r]));
+        for (int r = t; r < K; ++r) {
+            const T av = num<T>::abs(f[r]);
+            const bool gt = av > p;                              // strict: first maximum, like np.argmax
+            p = gt ? av : p;
+            kk = gt ? r : kk;
+        }
         bool isp[K];
-        bool taken = !found;
         T pj = T(1);
 #pragma unroll
-        for (int r = 0; r < K; ++r) {
-            const bool m = !used[r] && (num<T>::abs(f[r]) == p);
-            isp[r] = m && !taken;
-            taken = taken || m;
+        for (int r = t; r < K; ++r) {
+            isp[r] = found && (kk == r);
             pj = isp[r] ? f[r] : pj;
         }
-        const T inv = num<T>::rcp(pj);
-        T oh[K], g[K];
+        const T inv = num<T>::rcp(pj);                       // 1 when nothing was found
+        // ---- swap rows (pivot row <-> row t), as the reference does: picks the pivot row by a one-hot blend
+        // (row t itself when nothing was found), drops the old row t where the pivot row was
+        T oh[K];
 #pragma unroll
-        for (int r = 0; r < K; ++r) {
-            oh[r] = isp[r] ? inv : T(0);
-            g[r] = isp[r] ? f[r] - T(1) : f[r];
-        }
-        // ---- scaled pivot row (zero left of the pivot column and when nothing was found), fused update
+        for (int r = t; r < K; ++r) oh[r] = (isp[r] || (r == t && !found)) ? T(1) : T(0);
+        const T ft = f[t];
+#pragma unroll
+        for (int r = t + 1; r < K; ++r) f[r] = isp[r] ? ft : f[r];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            T pr = oh[0] * nb[s][0];
+            T rowp = oh[t] * nb[s][t];
 #pragma unroll
-            for (int r = 1; r < K; ++r) pr = num<T>::fma(oh[r], nb[s][r], pr);
-            pr = (col[s] >= jmin) ? pr : T(0);
+            for (int r = t + 1; r < K; ++r) rowp = num<T>::fma(oh[r], nb[s][r], rowp);
+            const T oldt = nb[s][t];
 #pragma unroll
-            for (int r = 0; r < K; ++r) nb[s][r] = num<T>::fma(-g[r], pr, nb[s][r]);
+            for (int r = t + 1; r < K; ++r) nb[s][r] = isp[r] ? oldt : nb[s][r];
+            // scaled pivot row: zero left of the pivot column (those columns are frozen, see the header comment)
+            const T pr = ((col[s] >= jmin) || !found) ? rowp * inv : T(0);
+            nb[s][t] = pr;
+#pragma unroll
+            for (int r = 0; r < K; ++r)
+                if (r != t) nb[s][r] = num<T>::fma(found ? -f[r] : T(0), pr, nb[s][r]);
         }
-#pragma unroll
-        for (int r = 0; r < K; ++r) {
-            used[r] = used[r] || isp[r];
-            jrow[r] = isp[r] ? jmin : jrow[r];
-            ar[r] = isp[r] ? alpha[t] : ar[r];
-        }
-        j0 = jmin + 1;
+        jrow[t] = jmin;
+        j0 = found ? jmin + 1 : j0;
     });
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         T v = T(0);
 #pragma unroll
-        for (int r = 0; r < K; ++r) v = num<T>::fma((jrow[r] <= col[s]) ? ar[r] : T(0), nb[s][r], v);
+        for (int r = 0; r < K; ++r) v = num<T>::fma((jrow[r] <= col[s]) ? alpha[r] : T(0), nb[s][r], v);
         out[s] = v;
     }
+}
+
+// ---- entry points.  float (production): everything inlined into the one straight-line kernel.  double (parity
+// build): the two big pieces are kept as real functions.  Reason: hipcc 7.2 miscompiles the fully inlined
+// k_step<double, Iiwa, 4, false> (512 VGPRs + 0.9 KB scratch: garbage in mu at -O3 and -O1 alike, while the same source
+// is exact as float, as double with HOLD = true, and as double with either piece outlined) -- found by
+// tests/test_gpu_parity.py::test_refresh_and_exact_bias_variants_against_oracle.  Outlining keeps the double kernels
+// far from the register ceiling; their speed is irrelevant.
+template <typename T, int M, int N, typename AF, typename YF>
+__device__ __attribute__((noinline)) void bidiag_solve_null_quad_out(AF& aget, YF& yget, T (&x)[(N + 3) / 4],
+                                                                     T (&nb)[(N + 3) / 4][N - M], const int lq) {
+    bidiag_solve_null_quad_inl<T, M, N>(aget, yget, x, nb, lq);
+}
+template <typename T, int M, int N, typename AF, typename YF>
+__device__ __forceinline__ void bidiag_solve_null_quad(AF&& aget, YF&& yget, T (&x)[(N + 3) / 4],
+                                                       T (&nb)[(N + 3) / 4][N - M], const int lq) {
+    if constexpr (std::is_same<T, double>::value) bidiag_solve_null_quad_out<T, M, N>(aget, yget, x, nb, lq);
+    else bidiag_solve_null_quad_inl<T, M, N>(aget, yget, x, nb, lq);
+}
+template <typename T, int N, int K>
+__device__ __attribute__((noinline)) void rref_apply_quad_out(T (&nb)[(N + 3) / 4][K], const T (&alpha)[K], T tol,
+                                                              T (&out)[(N + 3) / 4], const int lq) {
+    rref_apply_quad_inl<T, N, K>(nb, alpha, tol, out, lq);
+}
+template <typename T, int N, int K>
+__device__ __forceinline__ void rref_apply_quad(T (&nb)[(N + 3) / 4][K], const T (&alpha)[K], T tol,
+                                                T (&out)[(N + 3) / 4], const int lq) {
+    if constexpr (std::is_same<T, double>::value) rref_apply_quad_out<T, N, K>(nb, alpha, tol, out, lq);
+    else rref_apply_quad_inl<T, N, K>(nb, alpha, tol, out, lq);
 }
 
 }  // namespace atacom
