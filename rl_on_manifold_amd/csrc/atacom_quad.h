@@ -1,10 +1,11 @@
 // Quad-cooperative variant of the null-space solver: FOUR LANES PER ENVIRONMENT.
 //
-// Why (DESIGN.md "Kernel design", measured in profiles/): with one environment per lane the headline
-// batch of 8192 environments is only 128 wavefronts -- 1/8 of the chip's 1024 SIMDs, each running one
-// latency-bound dependent chain (~90 us per env step regardless of batch up to 65536).  Splitting every
-// environment over the 4 lanes of a DPP quad quarters the chain length, uses 4x the SIMDs at the same
-// batch, and costs only ~1.25x the total lane-work, so it is also competitive at large batch.
+// Why (measured in profiles/): a wave64 vector instruction occupies its SIMD for 4 clocks and a
+// lone wave already saturates it, so the step time is (vector instructions per wave) x ~5 clk.  With one environment
+// per lane the headline batch of 8192 environments is 128 wavefronts on 1024 SIMDs, each running the whole 24 k-
+// instruction step (52 us).  Splitting every environment over the 4 lanes of a DPP quad puts 512 waves to work at
+// ~0.6x the instructions per wave (30 us); beyond 16384 environments (1024 waves) the lane mapping wins again
+// because its total instruction count is lower.
 //
 // Data distribution inside a quad (lq = lane & 3):
 //   * matrices with N columns (J_c: M x N, null basis: N x K) are split BY COLUMN: column c lives in lane
@@ -12,10 +13,12 @@
 //   * vectors over the M rows (rhs y, the bidiagonal d / e, left reflectors u) are REPLICATED in the four
 //     lanes and computed redundantly -- their values stay bitwise identical across the quad because every
 //     cross-lane sum uses the same commutative butterfly;
-//   * cross-lane traffic is DPP only (quad_perm): a broadcast is one v_mov_dpp, a quad sum two v_add_dpp;
-//     no LDS, no ds_bpermute, no barriers.
-// The arithmetic is the same Householder bidiagonalisation / rref chart as atacom_linalg.h (which remains
-// the one-lane-per-env reference implementation); only the summation order inside dot products differs.
+//   * cross-lane traffic is DPP only (quad_perm): a broadcast is one v_mov_dpp, a quad sum two v_add_f32_dpp;
+//     no LDS, no ds_bpermute, no barriers;
+//   * "my column of a replicated array" is picked by a one-hot FMA blend, never by a select chain on lq (the
+//     optimiser turns those into a divergent 4-way switch).
+// The arithmetic is the same Householder bidiagonalisation / rref chart as atacom_linalg.h (the one-lane-per-env
+// implementation); only the summation order inside dot products differs.
 #pragma once
 #include "atacom_linalg.h"
 
