@@ -18,9 +18,9 @@ ARCH = 'gfx950'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + \
     os.environ.get('ATACOM_HIPCC_FLAGS', '').split()
 UNITS = ['atacom_circle.hip', 'atacom_planar.hip', 'atacom_iiwa.hip', 'atacom_capi.cpp']
-# per-unit scheduler choice, measured on MI355X (profiles/r01_lanes_vs_batch.md): the planar kernels have register
-# headroom and gain ~5 % from the ILP-first strategy; the iiwa quad kernel sits at the 256-VGPR limit and loses 8 %.
-UNIT_FLAGS = {'atacom_planar.hip': ['-mllvm', '-amdgpu-sched-strategy=max-ilp']}
+# per-unit extra flags (none at present: -amdgpu-sched-strategy=max-ilp was tried per unit -- planar step kernel -4 %,
+# planar policy-rollout kernel +19 %, iiwa quad kernel +8 % -- and dropped, profiles/r01_lanes_vs_batch.md)
+UNIT_FLAGS = {}
 
 
 def _sources():
