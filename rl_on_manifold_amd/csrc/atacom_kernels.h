@@ -148,12 +148,12 @@ __device__ __forceinline__ T device_uniform(unsigned int seed, int env, int epis
 // episode counter advances.  Returns with st.s valid (stored slack, or recomputed when q / dq were randomised).
 template <typename T, typename E>
 __device__ __forceinline__ void reset_env(const Params<T>& P, const T* __restrict__ f, int* __restrict__ ip, int B,
-                                          int b, EnvState<T, E>& st) {
+                                          int b, EnvState<T, E>& st, bool commit = true) {
     using L = Planes<E>;
     load_init<T, E>(f, B, b, st);
     if (!P.random_init) return;
     const int ep = ip[L::I_EP * (size_t)B + b];
-    ip[L::I_EP * (size_t)B + b] = ep + 1;
+    if (commit) ip[L::I_EP * (size_t)B + b] = ep + 1;     // commit = false: a lane shadowing another lane's environment
     if (E::ID == 0) {
         // circle_base.py:36-42
         const T y = T(-0.5) + T(1.5) * device_uniform<T>(P.seed, b, ep, 0);
@@ -526,6 +526,14 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
 
 // Row N2: rollout with the policy MLP evaluated in the kernel (atacom_policy.h).  d_actions_out receives the action
 // the policy drew (mean + std * noise, before the env's clip to [-1, 1]).
+// float + quad mapping: the network runs on the matrix cores (mlp_forward_mfma), one wavefront = 16 environments = one
+// GEMM column block.  Every lane of a live wave must then stay in the kernel (it supplies operand slices for ALL 16
+// environments), so lanes past the end of the batch shadow the last environment with their stores masked off.
+template <typename T, typename E, int LANES, int H>
+struct MlpPath {
+    static constexpr bool MFMA = std::is_same<T, float>::value && LANES == 4 && H == 64 && E::OBS <= 32 && E::NK <= 8;
+};
+
 template <typename T, typename E, int LANES, bool HOLD, int H>
 __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P, const MlpArgs<T> net, int n_steps,
                                                       T* __restrict__ f, int* __restrict__ ip,
@@ -534,14 +542,24 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P,
                                                       T* __restrict__ reward, uint8_t* __restrict__ absorbing,
                                                       uint8_t* __restrict__ last) {
     using L = Planes<E>;
+    constexpr bool MFMA = MlpPath<T, E, LANES, H>::MFMA;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* lds = reinterpret_cast<T*>(smem);
-    mlp_stage<T, E::OBS, H, E::NK>(net, lds, threadIdx.x, BLOCK<LANES>);
+    if constexpr (MFMA) mlp_stage_mfma<E::OBS, H, E::NK>(net, lds, threadIdx.x, BLOCK<LANES>, BLOCK<LANES> / WAVE);
+    else mlp_stage<T, E::OBS, H, E::NK>(net, lds, threadIdx.x, BLOCK<LANES>);
     const int B = P.batch;
     const int gt = blockIdx.x * BLOCK<LANES> + threadIdx.x;
-    const int b = gt / LANES;
+    const bool valid = gt / LANES < B;
+    if constexpr (MFMA) {
+        if ((gt & ~(WAVE - 1)) / LANES >= B) return;          // whole wavefront past the batch
+    } else {
+        if (!valid) return;
+    }
+    const int b = valid ? gt / LANES : B - 1;
     const int lq = gt % LANES;
-    if (b >= B) return;
+    const int lane = threadIdx.x & (WAVE - 1);
+    using LM = MlpLdsM<(E::OBS <= 32 ? E::OBS : 32), 64, (E::NK <= 8 ? E::NK : 8)>;
+    T* stage = lds + 2 * LM::NET + (threadIdx.x / WAVE) * LM::WAVE_STAGE;      // MFMA path only
     EnvState<T, E> st;
     load_state<T, E>(f, ip, B, b, st);
     T ssum = T(0), scmax = f[L::SCMAX * (size_t)B + b], sdq = f[L::SDQMAX * (size_t)B + b];
@@ -550,18 +568,25 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P,
         const size_t row = (size_t)t * B + b;
         T o[E::OBS];
         write_obs<T, E>(P, st, o);
-        T act[E::NK];
-        mlp_forward<T, E::OBS, H, E::NK, LANES>(lds, lds, o, net.activation, lq, act);
-        T sig[E::NK];
+        T act[E::NK], sig[E::NK];
+        if constexpr (MFMA) {
+            float xin[LM::CH];
+            mlp_obs_to_operand<E::OBS, H, E::NK>(lds, stage, o, lane, xin);
+            mlp_forward_mfma<E::OBS, H, E::NK>(lds, stage, xin, net.activation, lane, act);
+            if (net.sW1) mlp_forward_mfma<E::OBS, H, E::NK>(lds + LM::NET, stage, xin, net.activation, lane, sig);
+        } else {
+            mlp_forward<T, E::OBS, H, E::NK, LANES>(lds, lds, o, net.activation, lq, act);
+            if (net.sW1)
+                mlp_forward<T, E::OBS, H, E::NK, LANES>(lds + MlpLds<E::OBS, H, E::NK>::TOTAL, lds, o, net.activation, lq, sig);
+        }
         if (net.sW1) {
             // state-dependent sigma = exp(clamp(log_sigma_net(obs)))   (SAC)
-            mlp_forward<T, E::OBS, H, E::NK, LANES>(lds + MlpLds<E::OBS, H, E::NK>::TOTAL, lds, o, net.activation, lq, sig);
 #pragma unroll
             for (int k = 0; k < E::NK; ++k)
                 sig[k] = num<T>::exp(num<T>::min(num<T>::max(sig[k], net.log_std_min), net.log_std_max));
         } else {
 #pragma unroll
-            for (int k = 0; k < E::NK; ++k) sig[k] = lds[MlpLds<E::OBS, H, E::NK>::STD + k];
+            for (int k = 0; k < E::NK; ++k) sig[k] = lds[(MFMA ? (int)LM::STD : (int)MlpLds<E::OBS, H, E::NK>::STD) + k];
         }
 #pragma unroll
         for (int k = 0; k < E::NK; ++k) {
@@ -569,7 +594,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P,
             act[k] = num<T>::fma(sig[k], eps, act[k]);
             if (net.squash) act[k] = num<T>::tanh(act[k]);
         }
-        if (lq == 0) {
+        if (lq == 0 && valid) {
 #pragma unroll
             for (int i = 0; i < E::OBS; ++i) obs[row * E::OBS + i] = o[i];
 #pragma unroll
@@ -577,7 +602,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P,
         }
         StepOut<T> out;
         env_step<T, E, LANES, HOLD>(P, st, act, out, lq);
-        if (lq == 0) {
+        if (lq == 0 && valid) {
             if (next_obs) write_obs<T, E>(P, st, next_obs + row * E::OBS);
             reward[row] = out.reward;
             absorbing[row] = out.absorbing ? 1 : 0;
@@ -586,9 +611,9 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P,
         ssum += out.log_avg;
         scmax = num<T>::max(scmax, out.log_max);
         sdq = num<T>::max(sdq, out.log_dq);
-        if (P.auto_reset && out.last) reset_env<T, E>(P, f, ip, B, b, st);
+        if (P.auto_reset && out.last) reset_env<T, E>(P, f, ip, B, b, st, valid);
     }
-    if (lq != 0) return;
+    if (lq != 0 || !valid) return;
     f[L::SSUM * (size_t)B + b] += ssum;
     f[L::SCMAX * (size_t)B + b] = scmax;
     f[L::SDQMAX * (size_t)B + b] = sdq;

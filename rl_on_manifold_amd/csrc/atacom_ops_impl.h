@@ -79,7 +79,12 @@ struct Ops {
                            const void* noise, void* obs, void* nobs, void* acts, void* rew, uint8_t* ab,
                            uint8_t* last, hipStream_t s) {
         constexpr int H = 64;
-        const size_t lds_bytes = sizeof(T) * (((2 * MlpLds<E::OBS, H, E::NK>::TOTAL + 3) / 4) * 4);
+        size_t lds_floats = 2 * MlpLds<E::OBS, H, E::NK>::TOTAL;
+        if constexpr (MlpPath<T, E, LANES, H>::MFMA) {
+            using LM = MlpLdsM<E::OBS, H, E::NK>;
+            lds_floats = 2 * LM::NET + (BLOCK<LANES> / WAVE) * LM::WAVE_STAGE;
+        }
+        const size_t lds_bytes = sizeof(T) * (((lds_floats + 3) / 4) * 4);
         hipLaunchKernelGGL((k_rollout_mlp<T, E, LANES, HOLD, H>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)),
                            dim3(BLOCK<LANES>),
                            lds_bytes, s, make_params<T>(c), a, n_steps, (T*)f, ip, (const T*)noise, (T*)obs, (T*)nobs,

@@ -172,4 +172,178 @@ __device__ __forceinline__ void mlp_forward(const T* __restrict__ lds, const T* 
     (void)f2;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// MFMA form of the same network (float, quad mapping): one wavefront = 16 environments, and the three layers are
+// GEMMs of exactly the shape of v_mfma_f32_16x16x4_f32.  Computed TRANSPOSED,  H^T = W . X^T  (M = units,
+// N = the wave's 16 environments, K = inputs), because then the accumulator layout of one layer (lane l, register v
+// = unit 4 (l / 16) + v of environment l % 16) IS the B-operand layout of the next -- with the K index permuted,
+// which only changes where the A operand (a weight) is fetched from: W[row l % 16][16 t + 4 (l / 16) + v], four
+// consecutive floats per lane = one ds_read_b128 per four MFMAs.  So no re-layout between layers; the only shuffles
+// are the observation going in (quad-replicated -> [env][element], via 2 KB of per-wave LDS) and the NK action
+// means coming out.  100 MFMAs + ~50 LDS accesses per network and step, against ~0.75 k packed FMAs + 0.37 k LDS
+// reads in the VALU form above.  The fp32 MFMA rate equals the packed fp32 VALU rate on this chip; what is gained
+// is issue slots (one instruction per 1024 MACs) and LDS traffic, which is what a lone wave per SIMD runs out of.
+typedef float mfma_v4f __attribute__((ext_vector_type(4)));
+
+template <int D, int H, int NK>
+struct MlpLdsM {
+    static_assert(H == 64 && NK <= 8 && D <= 32, "MFMA policy path: 64 hidden units, <= 8 actions, <= 32 observations");
+    static constexpr int CH = (D + 3) / 4;       // observation elements per lane group = K-steps of layer 1
+    static constexpr int S1 = 32;                // W1 row: [lane group g][8] holding elements CH g + s
+    static constexpr int S2 = H + 4;             // W2 / W3 rows (k contiguous), padded against bank conflicts
+    static constexpr int W1 = 0, W2 = W1 + H * S1, W3 = W2 + H * S2, B1 = W3 + 16 * S2, B2 = B1 + H, B3 = B2 + H,
+                         SHIFT = B3 + 16, SCALE = SHIFT + 32, STD = SCALE + 32, NET = STD + 16;
+    static constexpr int XT = 0, ACT = 16 * 32, WAVE_STAGE = ACT + 16 * 8;      // per-wave staging (floats)
+};
+
+template <int D, int H, int NK>
+__device__ __forceinline__ void mlp_stage_weights_mfma(float* lds, const float* W1, const float* b1, const float* W2,
+                                                       const float* b2, const float* W3, const float* b3, int tid,
+                                                       int nthreads) {
+    using L = MlpLdsM<D, H, NK>;
+    for (int i = tid; i < H * D; i += nthreads) {
+        const int u = i / D, e = i % D;
+        lds[L::W1 + u * L::S1 + (e / L::CH) * 8 + (e % L::CH)] = W1[i];
+    }
+    for (int i = tid; i < H * H; i += nthreads) lds[L::W2 + (i / H) * L::S2 + (i % H)] = W2[i];
+    for (int i = tid; i < NK * H; i += nthreads) lds[L::W3 + (i / H) * L::S2 + (i % H)] = W3[i];
+    for (int i = tid; i < H; i += nthreads) { lds[L::B1 + i] = b1[i]; lds[L::B2 + i] = b2[i]; }
+    for (int i = tid; i < NK; i += nthreads) lds[L::B3 + i] = b3[i];
+}
+
+// LDS: [net 0][net 1 (sigma network, optional)][per-wave staging x nwaves]
+template <int D, int H, int NK>
+__device__ __forceinline__ void mlp_stage_mfma(const MlpArgs<float>& net, float* lds, int tid, int nthreads, int nwaves) {
+    using L = MlpLdsM<D, H, NK>;
+    const int total = 2 * L::NET + nwaves * L::WAVE_STAGE;
+    for (int i = tid; i < total; i += nthreads) lds[i] = 0.0f;
+    __syncthreads();
+    mlp_stage_weights_mfma<D, H, NK>(lds, net.W1, net.b1, net.W2, net.b2, net.W3, net.b3, tid, nthreads);
+    if (net.sW1)
+        mlp_stage_weights_mfma<D, H, NK>(lds + L::NET, net.sW1, net.sb1, net.sW2, net.sb2, net.sW3, net.sb3, tid, nthreads);
+    for (int i = tid; i < NK; i += nthreads) lds[L::STD + i] = net.std ? net.std[i] : 0.0f;
+    for (int i = tid; i < 32; i += nthreads) {
+        // [g][8] like W1; padding: shift 0, scale 1 (the padded observation elements are 0)
+        const int g = i / 8, s = i % 8, e = L::CH * g + s;
+        const bool real = s < L::CH && e < D;
+        lds[L::SHIFT + i] = (real && net.obs_shift) ? net.obs_shift[e] : 0.0f;
+        lds[L::SCALE + i] = (real && net.obs_scale) ? net.obs_scale[e] : 1.0f;
+    }
+    __syncthreads();
+}
+
+// wave-level ordering of LDS traffic between lanes of ONE wavefront: its DS instructions execute in program order,
+// so all that is needed is that the compiler keeps that order
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// activation of one lane's 16 accumulator entries; ONE wave-uniform branch per layer (per element it costs a branch
+// pair each)
+__device__ __forceinline__ void mlp_act16(mfma_v4f (&h)[4], int activation) {
+    if (activation == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) h[t][v] = num<float>::max(h[t][v], 0.0f);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) h[t][v] = num<float>::tanh(h[t][v]);
+    }
+}
+
+// xin[s] = normalised observation element CH g + s of environment (lane % 16)   (g = lane / 16): the B operand of
+// layer 1.  Staged by mlp_put_obs / fetched by this function's caller once per step, shared by both networks.
+template <int D, int H, int NK>
+__device__ __forceinline__ void mlp_forward_mfma(const float* __restrict__ net, float* __restrict__ stage,
+                                                 const float (&xin)[MlpLdsM<D, H, NK>::CH], int activation, int lane,
+                                                 float (&mean)[NK]) {
+    using L = MlpLdsM<D, H, NK>;
+    using V4 = mfma_v4f;
+    const int n16 = lane & 15, g = lane >> 4;
+    // ---- layer 1: acc[t][v] = unit 16 t + 4 g + v of environment n16
+    V4 h1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) h1[t] = *reinterpret_cast<const V4*>(net + L::B1 + 16 * t + 4 * g);
+    float w1[4][8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float* row = net + L::W1 + (16 * t + n16) * L::S1 + 8 * g;
+        const V4 lo = *reinterpret_cast<const V4*>(row);
+        const V4 hi = *reinterpret_cast<const V4*>(row + 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { w1[t][s] = lo[s]; w1[t][4 + s] = hi[s]; }
+    }
+#pragma unroll
+    for (int s = 0; s < L::CH; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[t][s], xin[s], h1[t], 0, 0, 0);
+    mlp_act16(h1, activation);
+    // ---- layer 2: K-step (t, v) carries unit 16 t + 4 g + v, i.e. register v of h1[t]
+    V4 h2[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) h2[u] = *reinterpret_cast<const V4*>(net + L::B2 + 16 * u + 4 * g);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        V4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = *reinterpret_cast<const V4*>(net + L::W2 + (16 * u + n16) * L::S2 + 16 * t + 4 * g);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) h2[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][v], h1[t][v], h2[u], 0, 0, 0);
+    }
+    mlp_act16(h2, activation);
+    // ---- output layer: rows >= NK of W3 are zero; two accumulators (even / odd k-tiles) halve the dependent chain
+    V4 oa = *reinterpret_cast<const V4*>(net + L::B3 + 4 * g), ob = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const V4 w = *reinterpret_cast<const V4*>(net + L::W3 + n16 * L::S2 + 16 * t + 4 * g);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            if ((t & 1) == 0) oa = __builtin_amdgcn_mfma_f32_16x16x4f32(w[v], h2[t][v], oa, 0, 0, 0);
+            else ob = __builtin_amdgcn_mfma_f32_16x16x4f32(w[v], h2[t][v], ob, 0, 0, 0);
+        }
+    }
+    oa += ob;                                   // lane (n16, g): outputs 4 g .. 4 g + 3 of environment n16
+    // ---- back to the quads: [env][8] through the wave's staging area
+    wave_lds_fence();
+    if (g < 2) *reinterpret_cast<V4*>(stage + L::ACT + n16 * 8 + 4 * g) = oa;
+    wave_lds_fence();
+    const float* mine = stage + L::ACT + (lane >> 2) * 8;
+    const V4 m0 = *reinterpret_cast<const V4*>(mine), m1 = *reinterpret_cast<const V4*>(mine + 4);
+#pragma unroll
+    for (int o = 0; o < NK; ++o) mean[o] = o < 4 ? m0[o < 4 ? o : 0] : m1[o >= 4 ? o - 4 : 0];
+    wave_lds_fence();
+}
+
+// observation of the quad's environment -> the wave's staging area -> B operand of layer 1 (normalised)
+template <int D, int H, int NK>
+__device__ __forceinline__ void mlp_obs_to_operand(const float* __restrict__ net0, float* __restrict__ stage,
+                                                   const float (&obs)[D], int lane,
+                                                   float (&xin)[MlpLdsM<D, H, NK>::CH]) {
+    using L = MlpLdsM<D, H, NK>;
+    using V4 = mfma_v4f;
+    const int n16 = lane & 15, g = lane >> 4;
+    float* row = stage + L::XT + (lane >> 2) * 32;          // the four lanes of a quad store identical values
+#pragma unroll
+    for (int q = 0; q < L::CH; ++q) {
+        V4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (4 * q + i < D) ? obs[4 * q + i < D ? 4 * q + i : 0] : 0.0f;
+        *reinterpret_cast<V4*>(row + 4 * q) = v;
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int s = 0; s < L::CH; ++s) {
+        const float raw = stage[L::XT + n16 * 32 + L::CH * g + s];
+        xin[s] = (raw - net0[L::SHIFT + 8 * g + s]) * net0[L::SCALE + 8 * g + s];
+    }
+    wave_lds_fence();
+}
+
 }  // namespace atacom

@@ -617,3 +617,29 @@ def test_chart_on_slack_structured_matrices(dt, lanes):
         assert (err / scale).max() < 1e-8
     else:
         assert ((err / scale) < 2e-3).mean() >= 0.98
+
+
+@pytest.mark.parametrize('name,key', [('planar', 'sac_planar'), ('iiwa', 'ppo_iiwa')])
+def test_policy_rollout_matrix_core_path_ragged_batch(golden, name, key):
+    """float + quad mapping evaluates the policy on the matrix cores, one wavefront = 16 environments; lanes past the
+    end of a batch that is not a multiple of 16 shadow the last environment with their stores masked.  Checked
+    against the one-env-per-lane kernel (VALU network) on a ragged batch with device-side random resets (the puck
+    positions drawn at every reset depend on the per-env episode counter, so a shadow lane committing a reset would
+    show): the same step / hit bookkeeping, and the same trajectories up to float32 summation order."""
+    B, T = 203, 7                                      # 203 = 12 * 16 + 11: a partial last wavefront
+    dev, _ = _policy_pair(golden, key)
+    k = SHAPES[name][2]
+    gen = torch.Generator(device=DEV); gen.manual_seed(5)
+    eps = torch.randn((T, B, k), device=DEV, generator=gen)
+    outs, states = [], []
+    for lanes in (4, 1):
+        env = _env(name, B, 'f32', lanes_per_env=lanes, auto_reset=True, horizon=3, random_init=True, seed=11)
+        outs.append(env.rollout_policy(dev, T, noise=eps))
+        states.append(env.get_state())
+    a, b = outs
+    assert torch.equal(a['last'], b['last'])
+    assert torch.equal(states[0][:, -1], states[1][:, -1])               # step counters
+    for kk in ('obs', 'action', 'reward'):
+        err = (a[kk] - b[kk]).abs().reshape(T, B, -1).amax(-1)
+        assert float(err.median()) < 2e-5, kk
+        assert float((err < 5e-3).float().mean()) >= 0.97, kk           # the rest: rref tolerance flips
