@@ -8,14 +8,14 @@
 // examples/iiwa_air_hockey_exp.py:32-34), the action is  mu(obs) + std * eps  (GaussianTorchPolicy, std_0 = 0.5,
 // examples/iiwa_air_hockey_exp.py:138-146) with eps supplied by the caller, so the kernel draws no random numbers.
 //
-// Mapping: weights are staged once per workgroup into LDS (26 KB in f32, rows padded so that the four lanes of
-// a quad hit different banks).  With 4 lanes per env the hidden units are interleaved over the quad (unit j ->
-// lane j % 4): layer 1 and 2 cost 1/4 each per lane, the hidden vector is re-assembled with DPP broadcasts, the
-// output layer is a partial dot product + quad sum.  Weights leave LDS as ds_read_b128 and meet the (paired)
-// activations as v_pk_fma_f32: ~0.75 k packed FMAs + 0.37 k LDS reads per network and env step.
-// MFMA was considered and rejected here: per wave the GEMM is only 16 x 64 x 64 and the A operand would have to
-// be re-laid-out from the quad-replicated observation through LDS on every step; the VALU form is ~10 % of the
-// step and needs no layout change.
+// Two implementations:
+//   * float + quad mapping (production): the three layers run on the matrix cores -- mlp_forward_mfma at the bottom of
+//     this file, one wavefront = 16 environments = one GEMM column block;
+//   * double (parity build) and the lane mapping: VALU form, mlp_forward.  Weights are staged once per workgroup into
+//     LDS (rows padded so that the four lanes of a quad hit different banks); with 4 lanes per env the hidden units are
+//     interleaved over the quad (unit j -> lane j % 4), the hidden vector is re-assembled with DPP broadcasts, the
+//     output layer is a partial dot product + quad sum; weights leave LDS as ds_read_b128 and meet the (paired)
+//     activations as v_pk_fma_f32.
 #pragma once
 #include "atacom_quad.h"
 
