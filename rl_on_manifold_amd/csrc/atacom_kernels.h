@@ -526,16 +526,23 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
 
 // Row N2: rollout with the policy MLP evaluated in the kernel (atacom_policy.h).  d_actions_out receives the action
 // the policy drew (mean + std * noise, before the env's clip to [-1, 1]).
-// float + quad mapping: the network runs on the matrix cores (mlp_forward_mfma), one wavefront = 16 environments = one
-// GEMM column block.  Every lane of a live wave must then stay in the kernel (it supplies operand slices for ALL 16
-// environments), so lanes past the end of the batch shadow the last environment with their stores masked off.
+// float: the network runs on the matrix cores (mlp_forward_mfma), one wavefront = 1 (quad mapping) or 4 (lane mapping)
+// GEMM column blocks of 16 environments.  Every lane of a live wave must then stay in the kernel (it supplies operand
+// slices for ALL environments of its blocks), so lanes past the end of the batch shadow the last environment with
+// their stores masked off.
 template <typename T, typename E, int LANES, int H>
 struct MlpPath {
-    static constexpr bool MFMA = std::is_same<T, float>::value && LANES == 4 && H == 64 && E::OBS <= 32 && E::NK <= 8;
+    static constexpr bool MFMA = std::is_same<T, float>::value && H == 64 && E::OBS <= 32 && E::NK <= 8;
+    static constexpr int NB = WAVE / (16 * LANES);        // blocks of 16 environments per wavefront
+    using LM = MlpLdsM<(E::OBS <= 32 ? E::OBS : 32), 64, (E::NK <= 8 ? E::NK : 8)>;
+    // 256-thread workgroups in both mappings: the staged weights (30 KB per network) are shared by 4 wavefronts; with
+    // one wave per workgroup the LDS footprint capped the lane mapping at 2 waves per CU (measured: 2x the time)
+    static constexpr int THREADS = 256;
+    static constexpr int STAGE = (THREADS / WAVE) * LM::wave_stage(NB);   // floats of per-wave staging per workgroup
 };
 
 template <typename T, typename E, int LANES, bool HOLD, int H>
-__global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P, const MlpArgs<T> net, int n_steps,
+__global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const MlpArgs<T> net, int n_steps,
                                                       T* __restrict__ f, int* __restrict__ ip,
                                                       const T* __restrict__ noise, T* __restrict__ obs,
                                                       T* __restrict__ next_obs, T* __restrict__ actions_out,
@@ -543,12 +550,13 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P,
                                                       uint8_t* __restrict__ last) {
     using L = Planes<E>;
     constexpr bool MFMA = MlpPath<T, E, LANES, H>::MFMA;
+    constexpr int THREADS = MlpPath<T, E, LANES, H>::THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* lds = reinterpret_cast<T*>(smem);
-    if constexpr (MFMA) mlp_stage_mfma<E::OBS, H, E::NK>(net, lds, threadIdx.x, BLOCK<LANES>, BLOCK<LANES> / WAVE);
-    else mlp_stage<T, E::OBS, H, E::NK>(net, lds, threadIdx.x, BLOCK<LANES>);
+    if constexpr (MFMA) mlp_stage_mfma<E::OBS, H, E::NK>(net, lds, threadIdx.x, THREADS, MlpPath<T, E, LANES, H>::STAGE);
+    else mlp_stage<T, E::OBS, H, E::NK>(net, lds, threadIdx.x, THREADS);
     const int B = P.batch;
-    const int gt = blockIdx.x * BLOCK<LANES> + threadIdx.x;
+    const int gt = blockIdx.x * THREADS + threadIdx.x;
     const bool valid = gt / LANES < B;
     if constexpr (MFMA) {
         if ((gt & ~(WAVE - 1)) / LANES >= B) return;          // whole wavefront past the batch
@@ -558,8 +566,10 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P,
     const int b = valid ? gt / LANES : B - 1;
     const int lq = gt % LANES;
     const int lane = threadIdx.x & (WAVE - 1);
-    using LM = MlpLdsM<(E::OBS <= 32 ? E::OBS : 32), 64, (E::NK <= 8 ? E::NK : 8)>;
-    T* stage = lds + 2 * LM::NET + (threadIdx.x / WAVE) * LM::WAVE_STAGE;      // MFMA path only
+    using LM = typename MlpPath<T, E, LANES, H>::LM;
+    constexpr int NB = MlpPath<T, E, LANES, H>::NB;
+    T* stage = lds + 2 * LM::NET + (threadIdx.x / WAVE) * LM::wave_stage(NB);  // MFMA path only
+    const int erow = lane / LANES;                                             // own environment within the wavefront
     EnvState<T, E> st;
     load_state<T, E>(f, ip, B, b, st);
     T ssum = T(0), scmax = f[L::SCMAX * (size_t)B + b], sdq = f[L::SDQMAX * (size_t)B + b];
@@ -570,10 +580,11 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout_mlp(const Params<T> P,
         write_obs<T, E>(P, st, o);
         T act[E::NK], sig[E::NK];
         if constexpr (MFMA) {
-            float xin[LM::CH];
-            mlp_obs_to_operand<E::OBS, H, E::NK>(lds, stage, o, lane, xin);
-            mlp_forward_mfma<E::OBS, H, E::NK>(lds, stage, xin, net.activation, lane, act);
-            if (net.sW1) mlp_forward_mfma<E::OBS, H, E::NK>(lds + LM::NET, stage, xin, net.activation, lane, sig);
+            float xin[NB][LM::CH];
+            mlp_obs_to_operand<E::OBS, H, E::NK, NB>(lds, stage, o, lane, erow, xin);
+            mlp_forward_mfma<E::OBS, H, E::NK, NB>(lds, stage, xin, net.activation, lane, erow, act);
+            if (net.sW1)
+                mlp_forward_mfma<E::OBS, H, E::NK, NB>(lds + LM::NET, stage, xin, net.activation, lane, erow, sig);
         } else {
             mlp_forward<T, E::OBS, H, E::NK, LANES>(lds, lds, o, net.activation, lq, act);
             if (net.sW1)

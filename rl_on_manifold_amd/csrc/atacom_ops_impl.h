@@ -81,12 +81,12 @@ struct Ops {
         constexpr int H = 64;
         size_t lds_floats = 2 * MlpLds<E::OBS, H, E::NK>::TOTAL;
         if constexpr (MlpPath<T, E, LANES, H>::MFMA) {
-            using LM = MlpLdsM<E::OBS, H, E::NK>;
-            lds_floats = 2 * LM::NET + (BLOCK<LANES> / WAVE) * LM::WAVE_STAGE;
+            using MP = MlpPath<T, E, LANES, H>;
+            lds_floats = 2 * MP::LM::NET + MP::STAGE;
         }
         const size_t lds_bytes = sizeof(T) * (((lds_floats + 3) / 4) * 4);
-        hipLaunchKernelGGL((k_rollout_mlp<T, E, LANES, HOLD, H>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)),
-                           dim3(BLOCK<LANES>),
+        constexpr int THREADS = MlpPath<T, E, LANES, H>::THREADS;
+        hipLaunchKernelGGL((k_rollout_mlp<T, E, LANES, HOLD, H>), dim3(nblk(c.batch * LANES, THREADS)), dim3(THREADS),
                            lds_bytes, s, make_params<T>(c), a, n_steps, (T*)f, ip, (const T*)noise, (T*)obs, (T*)nobs,
                            (T*)acts, (T*)rew, ab, last);
     }

@@ -193,7 +193,10 @@ struct MlpLdsM {
     static constexpr int S2 = H + 4;             // W2 / W3 rows (k contiguous), padded against bank conflicts
     static constexpr int W1 = 0, W2 = W1 + H * S1, W3 = W2 + H * S2, B1 = W3 + 16 * S2, B2 = B1 + H, B3 = B2 + H,
                          SHIFT = B3 + 16, SCALE = SHIFT + 32, STD = SCALE + 32, NET = STD + 16;
-    static constexpr int XT = 0, ACT = 16 * 32, WAVE_STAGE = ACT + 16 * 8;      // per-wave staging (floats)
+    // per-wave staging (floats) for NB blocks of 16 environments: observations [env][32], action means [env][8]
+    static constexpr int XT = 0;
+    static constexpr int act_offset(int nb) { return 16 * nb * 32; }
+    static constexpr int wave_stage(int nb) { return 16 * nb * (32 + 8); }
 };
 
 template <int D, int H, int NK>
@@ -213,9 +216,10 @@ __device__ __forceinline__ void mlp_stage_weights_mfma(float* lds, const float* 
 
 // LDS: [net 0][net 1 (sigma network, optional)][per-wave staging x nwaves]
 template <int D, int H, int NK>
-__device__ __forceinline__ void mlp_stage_mfma(const MlpArgs<float>& net, float* lds, int tid, int nthreads, int nwaves) {
+__device__ __forceinline__ void mlp_stage_mfma(const MlpArgs<float>& net, float* lds, int tid, int nthreads,
+                                               int stage_floats) {
     using L = MlpLdsM<D, H, NK>;
-    const int total = 2 * L::NET + nwaves * L::WAVE_STAGE;
+    const int total = 2 * L::NET + stage_floats;
     for (int i = tid; i < total; i += nthreads) lds[i] = 0.0f;
     __syncthreads();
     mlp_stage_weights_mfma<D, H, NK>(lds, net.W1, net.b1, net.W2, net.b2, net.W3, net.b3, tid, nthreads);
@@ -256,22 +260,26 @@ __device__ __forceinline__ void mlp_act16(mfma_v4f (&h)[4], int activation) {
     }
 }
 
-// xin[s] = normalised observation element CH g + s of environment (lane % 16)   (g = lane / 16): the B operand of
-// layer 1.  Staged by mlp_put_obs / fetched by this function's caller once per step, shared by both networks.
-template <int D, int H, int NK>
+// The wavefront's environments are processed as NB blocks of 16 (quad mapping: NB = 1, lane mapping: NB = 4); the A
+// operands (weights) are fetched once per layer tile and reused for every block.
+// xin[blk][s] = normalised observation element CH g + s of environment 16 blk + lane % 16   (g = lane / 16): the B
+// operand of layer 1, produced by mlp_obs_to_operand once per step and shared by both networks.
+// `erow` = this lane's own environment within the wavefront (quad mapping: lane / 4, lane mapping: lane).
+template <int D, int H, int NK, int NB>
 __device__ __forceinline__ void mlp_forward_mfma(const float* __restrict__ net, float* __restrict__ stage,
-                                                 const float (&xin)[MlpLdsM<D, H, NK>::CH], int activation, int lane,
-                                                 float (&mean)[NK]) {
+                                                 const float (&xin)[NB][MlpLdsM<D, H, NK>::CH], int activation,
+                                                 int lane, int erow, float (&mean)[NK]) {
     using L = MlpLdsM<D, H, NK>;
     using V4 = mfma_v4f;
     const int n16 = lane & 15, g = lane >> 4;
-    // ---- layer 1: acc[t][v] = unit 16 t + 4 g + v of environment n16
-    V4 h1[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) h1[t] = *reinterpret_cast<const V4*>(net + L::B1 + 16 * t + 4 * g);
+    // ---- layer 1: h1[blk][t][v] = unit 16 t + 4 g + v of environment 16 blk + n16
+    V4 h1[NB][4];
     float w1[4][8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+        const V4 bias = *reinterpret_cast<const V4*>(net + L::B1 + 16 * t + 4 * g);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) h1[blk][t] = bias;
         const float* row = net + L::W1 + (16 * t + n16) * L::S1 + 8 * g;
         const V4 lo = *reinterpret_cast<const V4*>(row);
         const V4 hi = *reinterpret_cast<const V4*>(row + 4);
@@ -281,12 +289,20 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* __restrict__ net, 
 #pragma unroll
     for (int s = 0; s < L::CH; ++s)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) h1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[t][s], xin[s], h1[t], 0, 0, 0);
-    mlp_act16(h1, activation);
-    // ---- layer 2: K-step (t, v) carries unit 16 t + 4 g + v, i.e. register v of h1[t]
-    V4 h2[4];
+        for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) h2[u] = *reinterpret_cast<const V4*>(net + L::B2 + 16 * u + 4 * g);
+            for (int t = 0; t < 4; ++t)
+                h1[blk][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[t][s], xin[blk][s], h1[blk][t], 0, 0, 0);
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) mlp_act16(h1[blk], activation);
+    // ---- layer 2: K-step (t, v) carries unit 16 t + 4 g + v, i.e. register v of h1[.][t]
+    V4 h2[NB][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const V4 bias = *reinterpret_cast<const V4*>(net + L::B2 + 16 * u + 4 * g);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) h2[blk][u] = bias;
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         V4 w[4];
@@ -295,41 +311,57 @@ __device__ __forceinline__ void mlp_forward_mfma(const float* __restrict__ net, 
 #pragma unroll
         for (int v = 0; v < 4; ++v)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) h2[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][v], h1[t][v], h2[u], 0, 0, 0);
+            for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    h2[blk][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[u][v], h1[blk][t][v], h2[blk][u], 0, 0, 0);
     }
-    mlp_act16(h2, activation);
-    // ---- output layer: rows >= NK of W3 are zero; two accumulators (even / odd k-tiles) halve the dependent chain
-    V4 oa = *reinterpret_cast<const V4*>(net + L::B3 + 4 * g), ob = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) mlp_act16(h2[blk], activation);
+    // ---- output layer: rows >= NK of W3 are zero; with one block, two accumulators (even / odd k-tiles) halve the
+    // dependent chain
+    V4 oa[NB], ob[NB];
+    {
+        const V4 bias = *reinterpret_cast<const V4*>(net + L::B3 + 4 * g);
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) { oa[blk] = bias; ob[blk] = V4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const V4 w = *reinterpret_cast<const V4*>(net + L::W3 + n16 * L::S2 + 16 * t + 4 * g);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            if ((t & 1) == 0) oa = __builtin_amdgcn_mfma_f32_16x16x4f32(w[v], h2[t][v], oa, 0, 0, 0);
-            else ob = __builtin_amdgcn_mfma_f32_16x16x4f32(w[v], h2[t][v], ob, 0, 0, 0);
-        }
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk) {
+                if ((t & 1) == 0 || NB > 1) oa[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[v], h2[blk][t][v], oa[blk], 0, 0, 0);
+                else ob[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[v], h2[blk][t][v], ob[blk], 0, 0, 0);
+            }
     }
-    oa += ob;                                   // lane (n16, g): outputs 4 g .. 4 g + 3 of environment n16
-    // ---- back to the quads: [env][8] through the wave's staging area
+    // ---- back to the owners: lane (n16, g) holds outputs 4 g .. 4 g + 3 of environment 16 blk + n16 -> [env][8]
+    float* act = stage + L::act_offset(NB);
     wave_lds_fence();
-    if (g < 2) *reinterpret_cast<V4*>(stage + L::ACT + n16 * 8 + 4 * g) = oa;
+    if (g < 2) {
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) *reinterpret_cast<V4*>(act + (16 * blk + n16) * 8 + 4 * g) = oa[blk] + ob[blk];
+    }
     wave_lds_fence();
-    const float* mine = stage + L::ACT + (lane >> 2) * 8;
+    const float* mine = act + erow * 8;
     const V4 m0 = *reinterpret_cast<const V4*>(mine), m1 = *reinterpret_cast<const V4*>(mine + 4);
 #pragma unroll
     for (int o = 0; o < NK; ++o) mean[o] = o < 4 ? m0[o < 4 ? o : 0] : m1[o >= 4 ? o - 4 : 0];
     wave_lds_fence();
 }
 
-// observation of the quad's environment -> the wave's staging area -> B operand of layer 1 (normalised)
-template <int D, int H, int NK>
+// observation of this lane's environment -> the wave's staging area -> B operands of layer 1 (normalised).  In the
+// quad mapping the four lanes of a quad store identical values to the same row.
+template <int D, int H, int NK, int NB>
 __device__ __forceinline__ void mlp_obs_to_operand(const float* __restrict__ net0, float* __restrict__ stage,
-                                                   const float (&obs)[D], int lane,
-                                                   float (&xin)[MlpLdsM<D, H, NK>::CH]) {
+                                                   const float (&obs)[D], int lane, int erow,
+                                                   float (&xin)[NB][MlpLdsM<D, H, NK>::CH]) {
     using L = MlpLdsM<D, H, NK>;
     using V4 = mfma_v4f;
     const int n16 = lane & 15, g = lane >> 4;
-    float* row = stage + L::XT + (lane >> 2) * 32;          // the four lanes of a quad store identical values
+    float* row = stage + L::XT + erow * 32;
 #pragma unroll
     for (int q = 0; q < L::CH; ++q) {
         V4 v;
@@ -340,8 +372,10 @@ __device__ __forceinline__ void mlp_obs_to_operand(const float* __restrict__ net
     wave_lds_fence();
 #pragma unroll
     for (int s = 0; s < L::CH; ++s) {
-        const float raw = stage[L::XT + n16 * 32 + L::CH * g + s];
-        xin[s] = (raw - net0[L::SHIFT + 8 * g + s]) * net0[L::SCALE + 8 * g + s];
+        const float sh = net0[L::SHIFT + 8 * g + s], sc = net0[L::SCALE + 8 * g + s];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+            xin[blk][s] = (stage[L::XT + (16 * blk + n16) * 32 + L::CH * g + s] - sh) * sc;
     }
     wave_lds_fence();
 }
