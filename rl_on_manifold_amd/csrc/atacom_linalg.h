@@ -278,7 +278,9 @@ __device__ __forceinline__ void bidiag_solve_null(AF&& aget, YF&& yget, T (&x)[N
 // (the tolerance test sees the same values: the candidates of column j are T V[:, j] restricted to unused rows).
 template <typename T, int K>
 struct ChartState {
-    T Tm[K][K];      // accumulated elimination steps
+    static constexpr int KP = (K + 1) / 2;   // rows of T as pairs (rows 2j, 2j+1; a zero row pads an odd K): the three
+                                             // K x K loops -- T col, the pivot row pick, the rank-1 update -- are packed
+    vec2<T> Tm2[KP][K];   // accumulated elimination steps
     T at[K];         // alpha~[r] = alpha[order of row r] for used rows, 0 for unused rows
     bool used[K];
     int cnt;
@@ -287,61 +289,75 @@ struct ChartState {
                      // indexed load, which forces the array into scratch memory -- one global round trip per column.)
     __device__ __forceinline__ void init(const T (&alpha)[K]) {
 #pragma unroll
-        for (int r = 0; r < K; ++r) {
+        for (int j = 0; j < KP; ++j)
 #pragma unroll
-            for (int c = 0; c < K; ++c) Tm[r][c] = (r == c) ? T(1) : T(0);
-            at[r] = T(0);
-            used[r] = false;
-        }
+            for (int c = 0; c < K; ++c) Tm2[j][c] = vec2<T>{(2 * j == c) ? T(1) : T(0), (2 * j + 1 == c) ? T(1) : T(0)};
+#pragma unroll
+        for (int r = 0; r < K; ++r) { at[r] = T(0); used[r] = false; }
         cnt = 0;
 #pragma unroll
         for (int k = 0; k < K; ++k) arem[k] = alpha[k];
     }
     // examine one column (raw entries col[K]); returns its (Nc alpha) value
     __device__ __forceinline__ T examine(const T (&col)[K], const T (&alpha)[K], T tol) {
-        T v[K];
+        using V2 = vec2<T>;
+        V2 v2[KP];
 #pragma unroll
-        for (int r = 0; r < K; ++r) {
-            T acc = Tm[r][0] * col[0];
+        for (int j = 0; j < KP; ++j) {
+            V2 acc = Tm2[j][0] * splat2(col[0]);
 #pragma unroll
-            for (int c = 1; c < K; ++c) acc = num<T>::fma(Tm[r][c], col[c], acc);
-            v[r] = acc;
+            for (int c = 1; c < K; ++c) acc = fma2(Tm2[j][c], splat2(col[c]), acc);
+            v2[j] = acc;
         }
         T p = T(-1), pv = T(1), dotv = T(0);
         int kk = 0;
 #pragma unroll
         for (int r = 0; r < K; ++r) {
-            const T av = used[r] ? T(-1) : num<T>::abs(v[r]);
+            const T vr = v2[r / 2][r % 2];
+            const T av = used[r] ? T(-1) : num<T>::abs(vr);
             const bool gt = av > p;                              // strict: first maximum, like np.argmax
             p = gt ? av : p;
             kk = gt ? r : kk;
-            pv = gt ? v[r] : pv;
-            dotv = num<T>::fma(at[r], v[r], dotv);
+            pv = gt ? vr : pv;
+            dotv = num<T>::fma(at[r], vr, dotv);
         }
         const bool piv = (cnt < K) && (p > tol);
         const T anext = arem[0];
         const T result = piv ? anext : dotv;
         if (__builtin_amdgcn_ballot_w64(piv) != 0ull) {           // wave-uniform: only ~K columns ever pivot
             const T invp = piv ? num<T>::rcp(pv) : T(0);         // lanes that do not pivot apply the identity
-            T rk[K], d[K];
+            // one-hot of the pivot row, scaled by 1 / pivot (all zero when this lane does not pivot), and the
+            // update factors d = v - e_pivot (0 for the pad row)
+            V2 ohi2[KP], d2[KP];
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                T oh[2], dd[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int r = 2 * j + i;
+                    const bool is_p = (r < K) && piv && (r == kk);
+                    oh[i] = is_p ? invp : T(0);
+                    dd[i] = (r < K) ? (is_p ? v2[j][i] - T(1) : v2[j][i]) : T(0);
+                    if (r < K) {
+                        at[r < K ? r : 0] = is_p ? anext : at[r < K ? r : 0];
+                        used[r < K ? r : 0] = used[r < K ? r : 0] || is_p;
+                    }
+                }
+                ohi2[j] = V2{oh[0], oh[1]};
+                d2[j] = V2{dd[0], dd[1]};
+            }
+            T rk[K];
 #pragma unroll
             for (int c = 0; c < K; ++c) {
-                T t = T(0);
+                V2 t = ohi2[0] * Tm2[0][c];
 #pragma unroll
-                for (int r = 0; r < K; ++r) t = (r == kk) ? Tm[r][c] : t;
-                rk[c] = t * invp;
+                for (int j = 1; j < KP; ++j) t = fma2(ohi2[j], Tm2[j][c], t);
+                rk[c] = t.x + t.y;
             }
 #pragma unroll
-            for (int r = 0; r < K; ++r) {
-                const bool is_p = piv && (r == kk);
-                d[r] = is_p ? v[r] - T(1) : v[r];
-                at[r] = is_p ? anext : at[r];
-                used[r] = used[r] || is_p;
-            }
+            for (int j = 0; j < KP; ++j)
 #pragma unroll
-            for (int r = 0; r < K; ++r)
-#pragma unroll
-                for (int c = 0; c < K; ++c) Tm[r][c] = num<T>::fma(-d[r], rk[c], Tm[r][c]);
+                for (int c = 0; c < K; ++c) Tm2[j][c] = fma2(-d2[j], splat2(rk[c]), Tm2[j][c]);
             cnt += piv ? 1 : 0;
 #pragma unroll
             for (int k = 0; k + 1 < K; ++k) arem[k] = piv ? arem[k + 1] : arem[k];
