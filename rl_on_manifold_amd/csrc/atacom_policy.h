@@ -147,7 +147,7 @@ __device__ __forceinline__ void mlp_forward(const T* __restrict__ lds, const T* 
         x2[i] = V2{h[0], h[1]};
     }
     T h1[U], h2[U];
-    V2 f1[H / 2], f2[H / 2];
+    V2 f1[H / 2];
     mlp_dense<T, D4, U, LANES>(lds + L::W1, L::S1, lds + L::B1, x2, activation, lq, h1);
     mlp_gather<T, H, LANES>(h1, f1);
     mlp_dense<T, H / 4, U, LANES>(lds + L::W2, L::S2, lds + L::B2, f1, activation, lq, h2);
@@ -169,7 +169,6 @@ __device__ __forceinline__ void mlp_forward(const T* __restrict__ lds, const T* 
         const T p = part[o / 2][o % 2];
         mean[o] = lds[L::B3 + o] + (LANES == 4 ? qsum(p) : p);
     }
-    (void)f2;
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -61,7 +61,6 @@ __device__ __forceinline__ T pick4(const T (&z)[LEN], int slot4, int lq) {
 }
 
 // ---- quad reductions / broadcasts of two-wide vectors (vec2, splat2, fma2: atacom_linalg.h)
-template <typename T> __device__ __forceinline__ vec2<T> qsum2(vec2<T> v) { return vec2<T>{qsum(v.x), qsum(v.y)}; }
 // float: the two butterfly levels of 2 / 4 / 6 independent quad sums written out as v_add_f32_dpp (DPP operand
 // folded into the add).  Left to itself the compiler pairs the halves into v_pk_add_f32, which cannot take a DPP
 // operand, so every level became 2 x v_mov_dpp + v_pk_add + an s_nop for the DPP read-after-write hazard (2
