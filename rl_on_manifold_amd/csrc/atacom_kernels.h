@@ -215,7 +215,8 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
     }
     T qc[NQ], dqc[NQ];          // what the controller sees (held over the sub-steps when hold_q)
     T m0x = T(0), m0y = T(0);   // mallet position at the start of the env step
-    T A[NC][NQ], psi[NC], c0[NC];
+    T A[NC][NQ], yb[NC];       // yb = psi + Kc c0: the slack-independent part of the right-hand side (one value
+                               // per row carried over the sub-steps instead of two)
     constexpr int SQ = (NN + 3) / 4;
     T Aq[NC][SQ];              // LANES == 4: this lane's columns of [K J | 0]
     auto prepare = [&](int sub) {
@@ -239,8 +240,9 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                     // reference's diag(K) @ J matmul does (the sign of a zero steers dlarfg's sign choice)
                     A[r][i] = num<T>::fma(P.K[r], J[r][i], T(0));
                 }
-                psi[r] = num<T>::fma(P.K[r], bst[r], jdq);      // constraints.py:42-43
-                c0[r] = num<T>::fma(P.K[r], jdq, fun[r]);       // constraints.py:33-37
+                const T psi = num<T>::fma(P.K[r], bst[r], jdq);      // constraints.py:42-43
+                const T c0 = num<T>::fma(P.K[r], jdq, fun[r]);       // constraints.py:33-37
+                yb[r] = (E::MODE == 1) ? P.Kc[r] * c0 : num<T>::fma(P.Kc[r], c0, psi);   // E: no drift term (:127)
             }
             if (LANES == 4) {
                 // this lane's columns of K J: a one-hot blend over the quad (exact: the mask is 0 / 1 and the entries
@@ -275,8 +277,8 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
 #pragma unroll
         for (int r = 0; r < NC; ++r) {
             const T sv = (r >= NF) ? st.s[r >= NF ? r - NF : 0] : T(0);
-            const T cs = num<T>::fma(T(0.5) * sv, sv, c0[r]);         // c = fun + K J dq (+ s^2 / 2 on g rows)
-            y[r] = (E::MODE == 1) ? P.Kc[r] * cs : num<T>::fma(P.Kc[r], cs, psi[r]);     // E: no drift term (:127)
+            // rhs = psi + Kc c,  c = fun + K J dq (+ s^2 / 2 on the g rows)
+            y[r] = (r >= NF) ? num<T>::fma(T(0.5) * P.Kc[r] * sv, sv, yb[r]) : yb[r];
         }
         if (LANES == 1 || E::MODE != 0) {
             T x[NN], nb[NN][NN - NC], nmu[NN];
