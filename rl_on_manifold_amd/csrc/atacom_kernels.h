@@ -19,7 +19,7 @@ namespace atacom {
 constexpr int WAVE = 64;
 // threads per workgroup of the step / rollout kernels: the quad mapping runs 2.7 % faster with four waves per
 // workgroup (one per SIMD of a CU, sharing the instruction cache), the lane mapping with one (measured, profiles/)
-template <int LANES> constexpr int BLOCK = (LANES == 4) ? 256 : 64;
+template <int LANES> constexpr int BLOCK = (LANES > 1) ? 256 : 64;
 
 // ------------------------------------------------------------------ plane layout of the state buffer
 template <typename E>
@@ -217,8 +217,8 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
     T m0x = T(0), m0y = T(0);   // mallet position at the start of the env step
     T A[NC][NQ], yb[NC];       // yb = psi + Kc c0: the slack-independent part of the right-hand side (one value
                                // per row carried over the sub-steps instead of two)
-    constexpr int SQ = (NN + 3) / 4;
-    T Aq[NC][SQ];              // LANES == 4: this lane's columns of [K J | 0]
+    constexpr int SQ = (NN + LANES - 1) / LANES;
+    T Aq[NC][SQ];              // LANES > 1: this lane's columns of [K J | 0]
     auto prepare = [&](int sub) {
 #pragma unroll
             for (int i = 0; i < NQ; ++i) { qc[i] = st.q[i]; dqc[i] = st.dq[i]; }
@@ -244,22 +244,22 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 const T c0 = num<T>::fma(P.K[r], jdq, fun[r]);       // constraints.py:33-37
                 yb[r] = (E::MODE == 1) ? P.Kc[r] * c0 : num<T>::fma(P.Kc[r], c0, psi);   // E: no drift term (:127)
             }
-            if (LANES == 4) {
-                // this lane's columns of K J: a one-hot blend over the quad (exact: the mask is 0 / 1 and the entries
-                // carry no -0 after the fma above).  Written as arithmetic on purpose -- a `lq == l ? ... : ...`
-                // select chain over all rows is turned into a 4-way divergent switch by the optimiser (measured:
-                // 350 instructions for this block).
-                T oh[4];
+            if (LANES > 1) {
+                // this lane's columns of K J: a one-hot blend over the lane group (exact: the mask is 0 / 1 and the
+                // entries carry no -0 after the fma above).  Written as arithmetic on purpose -- a `lq == l ? ... : ...`
+                // select chain over all rows is turned into a divergent switch by the optimiser (measured: 350
+                // instructions for this block).
+                T oh[LANES];
 #pragma unroll
-                for (int l = 0; l < 4; ++l) oh[l] = (lq == l) ? T(1) : T(0);
+                for (int l = 0; l < LANES; ++l) oh[l] = (lq == l) ? T(1) : T(0);
 #pragma unroll
                 for (int r = 0; r < NC; ++r)
 #pragma unroll
                     for (int sl = 0; sl < SQ; ++sl) {
                         T v = T(0);
 #pragma unroll
-                        for (int l = 0; l < 4; ++l)
-                            if (4 * sl + l < NQ) v = num<T>::fma(oh[l], A[r][4 * sl + l < NQ ? 4 * sl + l : 0], v);
+                        for (int l = 0; l < LANES; ++l)
+                            if (LANES * sl + l < NQ) v = num<T>::fma(oh[l], A[r][LANES * sl + l < NQ ? LANES * sl + l : 0], v);
                         Aq[r][sl] = v;
                     }
             }
@@ -303,31 +303,31 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 for (int n = 0; n < NN; ++n) mu[n] = nmu[n] - x[n];           // atacom.py:130-133
             }
         } else {
-            constexpr int S = (NN + 3) / 4;
+            constexpr int LG = LANES > 1 ? LANES : 4;        // lanes per environment (this branch: 2 or 4)
+            constexpr int S = (NN + LG - 1) / LG;
             constexpr int ND = NN - NC;
             T x[S], nb[S][ND], nmu[S];
             T alphaq[ND];
 #pragma unroll
             for (int k = 0; k < ND; ++k) alphaq[k] = alpha[k < NK ? k : 0];
             // this lane's columns: the K J block was split once per step (Aq), the slack diagonal entry of
-            // row r sits in column NQ + r - NF, i.e. slot (NQ+r-NF)/4 of lane (NQ+r-NF)%4
+            // row r sits in column NQ + r - NF, i.e. slot (NQ+r-NF)/LG of lane (NQ+r-NF)%LG
             auto aget = [&](auto rc, auto sc) -> T {
                 constexpr int r = decltype(rc)::value, sl = decltype(sc)::value;
                 const T base = Aq[r][sl];
                 if constexpr (r >= NF) {
                     constexpr int c = NQ + r - NF;
-                    if constexpr (c / 4 == sl) return (lq == c % 4) ? st.s[r - NF] : base;
+                    if constexpr (c / LG == sl) return (lq == c % LG) ? st.s[r - NF] : base;
                 }
                 return base;
             };
             auto yget = [&](auto rc) -> T { return y[decltype(rc)::value]; };
-            bidiag_solve_null_quad<T, NC, NN>(aget, yget, x, nb, lq);
-            rref_apply_quad<T, NN, ND>(nb, alphaq, P.rref_tol, nmu, lq);
-#pragma unroll
-            for (int n = 0; n < NN; ++n) {                          // gather mu back to every lane of the quad
-                const T o = nmu[n / 4] - x[n / 4];
-                mu[n] = (n % 4 == 0) ? qbcast<0>(o) : (n % 4 == 1) ? qbcast<1>(o) : (n % 4 == 2) ? qbcast<2>(o) : qbcast<3>(o);
-            }
+            bidiag_solve_null_quad<T, NC, NN, LG>(aget, yget, x, nb, lq);
+            rref_apply_quad<T, NN, ND, LG>(nb, alphaq, P.rref_tol, nmu, lq);
+            static_for<0, NN>([&](auto nc) {                        // gather mu back to every lane of the group
+                constexpr int n = decltype(nc)::value;
+                mu[n] = qbcast<n % LG, LG>(nmu[n / LG] - x[n / LG]);
+            });
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) st.s[g] = num<T>::fma(mu[NQ + g], P.dt, st.s[g]);   // :135
@@ -811,26 +811,26 @@ __global__ void __launch_bounds__(WAVE) k_nullspace(int n, const T* __restrict__
     }
 }
 
-// the same primitive through the quad-cooperative solver (4 lanes per matrix)
-template <typename T, typename E>
+// the same primitive through the lane-group solver (LN = 4 or 2 lanes per matrix)
+template <typename T, typename E, int LN>
 __global__ void __launch_bounds__(WAVE) k_nullspace_quad(int n, const T* __restrict__ Jc, const T* __restrict__ rhs,
                                                          T tol, T* __restrict__ xo, T* __restrict__ nullo,
                                                          T* __restrict__ rrefo) {
-    constexpr int NC = E::NC, NN = E::NN, NK = E::NN - E::NC, S = (NN + 3) / 4;
+    constexpr int NC = E::NC, NN = E::NN, NK = E::NN - E::NC, S = (NN + LN - 1) / LN;
     const int gt = blockIdx.x * WAVE + threadIdx.x;
-    const int b = gt >> 2, lq = gt & 3;
+    const int b = gt / LN, lq = gt % LN;
     if (b >= n) return;
     T x[S], nb[S][NK];
     auto aget = [&](auto rc, auto sc) -> T {
         constexpr int r = decltype(rc)::value, sl = decltype(sc)::value;
-        const int c = 4 * sl + lq;
+        const int c = LN * sl + lq;
         return (c < NN) ? Jc[((size_t)b * NC + r) * NN + (c < NN ? c : 0)] : T(0);
     };
     auto yget = [&](auto rc) -> T { return rhs ? rhs[(size_t)b * NC + decltype(rc)::value] : T(0); };
-    bidiag_solve_null_quad<T, NC, NN>(aget, yget, x, nb, lq);
+    bidiag_solve_null_quad<T, NC, NN, LN>(aget, yget, x, nb, lq);
 #pragma unroll
     for (int sl = 0; sl < S; ++sl) {
-        const int c = 4 * sl + lq;
+        const int c = LN * sl + lq;
         if (c < NN) {
             if (xo) xo[(size_t)b * NN + c] = x[sl];
             if (nullo) {
@@ -849,10 +849,10 @@ __global__ void __launch_bounds__(WAVE) k_nullspace_quad(int n, const T* __restr
                 for (int j = 0; j < NK; ++j) nb2[sl][j] = nb[sl][j];
 #pragma unroll
             for (int j = 0; j < NK; ++j) alpha[j] = (j == k) ? T(1) : T(0);
-            rref_apply_quad<T, NN, NK>(nb2, alpha, tol, col, lq);
+            rref_apply_quad<T, NN, NK, LN>(nb2, alpha, tol, col, lq);
 #pragma unroll
             for (int sl = 0; sl < S; ++sl) {
-                const int c = 4 * sl + lq;
+                const int c = LN * sl + lq;
                 if (c < NN) rrefo[((size_t)b * NN + c) * NK + k] = col[sl];
             }
         }

@@ -39,7 +39,7 @@ static inline int nblk(int n, int per) { return (n + per - 1) / per; }
 template <typename T, typename E>
 struct Ops {
     using L = Planes<E>;
-    // kernel variants: LANES in {1, 4} x HOLD in {true, false}
+    // kernel variants: LANES in {1, 2, 4} x HOLD in {true, false}
     template <int LANES, bool HOLD>
     static void launch_step(const atacom_config& c, void* f, int* ip, const void* act, void* obs, void* rew,
                             uint8_t* ab, uint8_t* last, hipStream_t s) {
@@ -52,6 +52,9 @@ struct Ops {
         if (lanes == 4) {
             if (c.hold_q) launch_step<4, true>(c, f, ip, act, obs, rew, ab, last, s);
             else launch_step<4, false>(c, f, ip, act, obs, rew, ab, last, s);
+        } else if (lanes == 2) {
+            if (c.hold_q) launch_step<2, true>(c, f, ip, act, obs, rew, ab, last, s);
+            else launch_step<2, false>(c, f, ip, act, obs, rew, ab, last, s);
         } else {
             if (c.hold_q) launch_step<1, true>(c, f, ip, act, obs, rew, ab, last, s);
             else launch_step<1, false>(c, f, ip, act, obs, rew, ab, last, s);
@@ -69,6 +72,9 @@ struct Ops {
         if (lanes == 4) {
             if (c.hold_q) launch_rollout<4, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
             else launch_rollout<4, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
+        } else if (lanes == 2) {
+            if (c.hold_q) launch_rollout<2, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
+            else launch_rollout<2, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
         } else {
             if (c.hold_q) launch_rollout<1, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
             else launch_rollout<1, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
@@ -106,6 +112,9 @@ struct Ops {
             if (lanes == 4) {
                 if (c.hold_q) launch_mlp<4, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
                 else launch_mlp<4, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
+            } else if (lanes == 2) {
+                if (c.hold_q) launch_mlp<2, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
+                else launch_mlp<2, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
             } else {
                 if (c.hold_q) launch_mlp<1, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
                 else launch_mlp<1, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
@@ -140,7 +149,10 @@ struct Ops {
     static void nullspace(int lanes, int n, const void* Jc, const void* rhs, double tol, void* x, void* nullb,
                           void* rref, hipStream_t s) {
         if (lanes == 4)
-            hipLaunchKernelGGL((k_nullspace_quad<T, E>), dim3(nblk(n * 4, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,
+            hipLaunchKernelGGL((k_nullspace_quad<T, E, 4>), dim3(nblk(n * 4, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,
+                               (const T*)rhs, (T)tol, (T*)x, (T*)nullb, (T*)rref);
+        else if (lanes == 2)
+            hipLaunchKernelGGL((k_nullspace_quad<T, E, 2>), dim3(nblk(n * 2, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,
                                (const T*)rhs, (T)tol, (T*)x, (T*)nullb, (T*)rref);
         else
             hipLaunchKernelGGL((k_nullspace<T, E>), dim3(nblk(n, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,

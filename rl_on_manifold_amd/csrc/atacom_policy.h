@@ -119,6 +119,9 @@ __device__ __forceinline__ void mlp_gather(const T (&h)[H / LANES], vec2<T> (&fu
             full[2 * m] = V2{qbcast<0>(h[m]), qbcast<1>(h[m])};
             full[2 * m + 1] = V2{qbcast<2>(h[m]), qbcast<3>(h[m])};
         }
+    } else if constexpr (LANES == 2) {
+#pragma unroll
+        for (int m = 0; m < H / 2; ++m) full[m] = V2{qbcast<0, 2>(h[m]), qbcast<1, 2>(h[m])};
     } else {
 #pragma unroll
         for (int m = 0; m < H / 2; ++m) full[m] = V2{h[2 * m], h[2 * m + 1]};
@@ -167,7 +170,7 @@ __device__ __forceinline__ void mlp_forward(const T* __restrict__ lds, const T* 
 #pragma unroll
     for (int o = 0; o < NK; ++o) {
         const T p = part[o / 2][o % 2];
-        mean[o] = lds[L::B3 + o] + (LANES == 4 ? qsum(p) : p);
+        mean[o] = lds[L::B3 + o] + (LANES > 1 ? qsum<(LANES > 1 ? LANES : 4)>(p) : p);
     }
 }
 

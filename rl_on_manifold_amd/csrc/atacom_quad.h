@@ -40,22 +40,31 @@ __device__ __forceinline__ int dpp_mov(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 
-// value of lane O (0..3) of the quad, in all four lanes
-template <int O, typename V>
-__device__ __forceinline__ V qbcast(V v) { return dpp_mov<O * 0x55>(v); }
-// sum over the quad, identical bits in all four lanes
-template <typename T>
+// Everything below is written for a GROUP of LN lanes per environment: LN = 4 (a DPP quad) or LN = 2 (a lane pair, two
+// environments per quad).  The pair form has half the redundancy and one butterfly level instead of two; it is the
+// mapping of choice when there are enough environments to fill the chip with 32-env waves but not with 64-env waves.
+//
+// value of lane O (0..LN-1) of the group, in all its lanes
+template <int O, int LN = 4, typename V>
+__device__ __forceinline__ V qbcast(V v) {
+    static_assert(LN == 4 || LN == 2, "");
+    // quad_perm: LN = 4 -> [O,O,O,O];  LN = 2 -> [O,O,2+O,2+O]
+    return dpp_mov<(LN == 4) ? O * 0x55 : (O * 0x05 + (2 + O) * 0x50)>(v);
+}
+// sum over the group, identical bits in all its lanes
+template <int LN = 4, typename T>
 __device__ __forceinline__ T qsum(T v) {
     const T s1 = v + dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
-    return s1 + dpp_mov<0x4E>(s1);         // quad_perm [2,3,0,1]
+    if constexpr (LN == 2) return s1;
+    else return s1 + dpp_mov<0x4E>(s1);    // quad_perm [2,3,0,1]
 }
-// element 4*slot + lq of a replicated compile-time-indexed array (0 past its end), as a one-hot blend over the
-// quad (exact for finite inputs; a select chain on lq tends to be lowered to a divergent switch)
-template <typename T, int LEN>
+// element LN*slot + lq of a replicated compile-time-indexed array (0 past its end), as a one-hot blend over the
+// group (exact for finite inputs; a select chain on lq tends to be lowered to a divergent switch)
+template <typename T, int LEN, int LN = 4>
 __device__ __forceinline__ T pick4(const T (&z)[LEN], int slot4, int lq) {
     T v = T(0);
 #pragma unroll
-    for (int l = 0; l < 4; ++l)
+    for (int l = 0; l < LN; ++l)
         if (slot4 + l < LEN) v = num<T>::fma((lq == l) ? T(1) : T(0), z[slot4 + l < LEN ? slot4 + l : 0], v);
     return v;
 }
@@ -92,6 +101,32 @@ __device__ __forceinline__ void qsum_n(float& a, float& b, float& c, float& d, f
         "v_add_f32_dpp %4, %4, %4" ATACOM_DPP_X2 "v_add_f32_dpp %5, %5, %5" ATACOM_DPP_X2
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
 }
+// lane pairs: one butterfly level
+__device__ __forceinline__ void psum_n(float& a, float& b) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0" ATACOM_DPP_X1 "v_add_f32_dpp %1, %1, %1" ATACOM_DPP_X1
+        : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void psum_n(float& a, float& b, float& c, float& d) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0" ATACOM_DPP_X1 "v_add_f32_dpp %1, %1, %1" ATACOM_DPP_X1
+        "v_add_f32_dpp %2, %2, %2" ATACOM_DPP_X1 "v_add_f32_dpp %3, %3, %3" ATACOM_DPP_X1
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void psum_n(float& a, float& b, float& c, float& d, float& e, float& f) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0" ATACOM_DPP_X1 "v_add_f32_dpp %1, %1, %1" ATACOM_DPP_X1
+        "v_add_f32_dpp %2, %2, %2" ATACOM_DPP_X1 "v_add_f32_dpp %3, %3, %3" ATACOM_DPP_X1
+        "v_add_f32_dpp %4, %4, %4" ATACOM_DPP_X1 "v_add_f32_dpp %5, %5, %5" ATACOM_DPP_X1
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+}
+__device__ __forceinline__ void psum_n(double& a, double& b) { a = qsum<2>(a); b = qsum<2>(b); }
+__device__ __forceinline__ void psum_n(double& a, double& b, double& c, double& d) {
+    a = qsum<2>(a); b = qsum<2>(b); c = qsum<2>(c); d = qsum<2>(d);
+}
+__device__ __forceinline__ void psum_n(double& a, double& b, double& c, double& d, double& e, double& f) {
+    a = qsum<2>(a); b = qsum<2>(b); c = qsum<2>(c); d = qsum<2>(d); e = qsum<2>(e); f = qsum<2>(f);
+}
 __device__ __forceinline__ void qsum_n(double& a, double& b) { a = qsum(a); b = qsum(b); }
 __device__ __forceinline__ void qsum_n(double& a, double& b, double& c, double& d) {
     a = qsum(a); b = qsum(b); c = qsum(c); d = qsum(d);
@@ -99,24 +134,28 @@ __device__ __forceinline__ void qsum_n(double& a, double& b, double& c, double& 
 __device__ __forceinline__ void qsum_n(double& a, double& b, double& c, double& d, double& e, double& f) {
     a = qsum(a); b = qsum(b); c = qsum(c); d = qsum(d); e = qsum(e); f = qsum(f);
 }
-// quad sums of the halves of CNT (1..3) two-wide vectors, in place
-template <int CNT, typename T>
+// group sums of the halves of CNT (1..3) two-wide vectors, in place
+template <int CNT, typename T, int LN = 4>
 __device__ __forceinline__ void qsum_pairs(vec2<T> (&w)[CNT]) {
     static_assert(CNT >= 1 && CNT <= 3, "");
     T h[2 * CNT];
 #pragma unroll
     for (int j = 0; j < CNT; ++j) { h[2 * j] = w[j].x; h[2 * j + 1] = w[j].y; }
-    if constexpr (CNT == 1) qsum_n(h[0], h[1]);
+    if constexpr (LN == 2) {
+        if constexpr (CNT == 1) psum_n(h[0], h[1]);
+        else if constexpr (CNT == 2) psum_n(h[0], h[1], h[2], h[3]);
+        else psum_n(h[0], h[1], h[2], h[3], h[4], h[5]);
+    } else if constexpr (CNT == 1) qsum_n(h[0], h[1]);
     else if constexpr (CNT == 2) qsum_n(h[0], h[1], h[2], h[3]);
     else qsum_n(h[0], h[1], h[2], h[3], h[4], h[5]);
 #pragma unroll
     for (int j = 0; j < CNT; ++j) w[j] = vec2<T>{h[2 * j], h[2 * j + 1]};
 }
-template <int O, typename T> __device__ __forceinline__ vec2<T> qbcast2(vec2<T> v) {
-    return vec2<T>{qbcast<O>(v.x), qbcast<O>(v.y)};
+template <int O, int LN = 4, typename T> __device__ __forceinline__ vec2<T> qbcast2(vec2<T> v) {
+    return vec2<T>{qbcast<O, LN>(v.x), qbcast<O, LN>(v.y)};
 }
-// value held by lane L (compile time) of the quad
-template <int L, typename V> __device__ __forceinline__ V qfrom(V v) { return qbcast<L>(v); }
+// value held by lane L (compile time) of the group
+template <int L, int LN = 4, typename V> __device__ __forceinline__ V qfrom(V v) { return qbcast<L, LN>(v); }
 
 // a: M x N split by column over the quad (a[r][slot] = A[r][4*slot+lq], zeros past N); y replicated.
 // On return x[slot] and nb[slot][k] are the column-split  A^+ y  and orthonormal null basis (see
@@ -125,10 +164,10 @@ template <int L, typename V> __device__ __forceinline__ V qfrom(V v) { return qb
 // compile-time indices (std::integral_constant), so the operands are born in their register pairs: an
 // intermediate T a[M][S] array here made the optimiser merge neighbouring stores and then fail to dissolve the
 // array, which put it in scratch / LDS (+10 us per step, measured).
-template <typename T, int M, int N, typename AF, typename YF>
-__device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, YF&& yget, T (&x)[(N + 3) / 4],
-                                                       T (&nb)[(N + 3) / 4][N - M], const int lq) {
-    constexpr int S = (N + 3) / 4, K = N - M;
+template <typename T, int M, int N, int LN, typename AF, typename YF>
+__device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, YF&& yget, T (&x)[(N + LN - 1) / LN],
+                                                       T (&nb)[(N + LN - 1) / LN][N - M], const int lq) {
+    constexpr int S = (N + LN - 1) / LN, K = N - M;
     constexpr int MP = (M + 1) / 2;          // row pairs (a zero row pads an odd M: it is a fixed point of every step)
     constexpr int KP = (K + 2) / 2;          // pairs over the K null vectors + x
     using V2 = vec2<T>;
@@ -150,7 +189,7 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, YF&& yget,
     T d[M], e[M], taup[M];
     static_for<0, M>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        constexpr int si = i / 4, li = i % 4;      // column i lives in slot si of lane li
+        constexpr int si = i / LN, li = i % LN;    // column i lives in slot si of lane li
         constexpr int pi = i / 2, hi = i % 2;      // row i is half hi of row pair pi
         // ---- right reflector G(i) from row i, columns > i
         T vrow[S];
@@ -159,8 +198,8 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, YF&& yget,
         T part = (lq > li) ? vrow[si] * vrow[si] : T(0);
 #pragma unroll
         for (int s = si + 1; s < S; ++s) part = num<T>::fma(vrow[s], vrow[s], part);
-        const T ss = qsum(part);
-        const T alpha = qfrom<li>(vrow[si]);
+        const T ss = qsum<LN>(part);
+        const T alpha = qfrom<li, LN>(vrow[si]);
         T beta, tp;
         const T sc = larfg_scale(alpha, ss, beta, tp);
         d[i] = beta;
@@ -186,7 +225,7 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, YF&& yget,
 #pragma unroll
                     for (int s = si + 1; s < S; ++s) w[j] = fma2(a2[s][pa + j], splat2(vrow[s]), w[j]);
                 }
-                qsum_pairs<CNT, T>(w);
+                qsum_pairs<CNT, T, LN>(w);
 #pragma unroll
                 for (int j = 0; j < CNT; ++j) {
                     w[j] *= splat2(tp);
@@ -202,14 +241,14 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, YF&& yget,
             for (int p = p0 + 1; p < MP; ++p) sq = fma2(a2[si][p], a2[si][p], sq);
             T sup = sq.x + sq.y;
             if constexpr (hi == 1) sup = num<T>::fma(a2[si][p0].y, a2[si][p0].y, sup);   // row i+2 shares i+1's pair
-            const T su = qfrom<li>(sup);
-            const T alq = qfrom<li>(hi == 0 ? a2[si][p0].y : a2[si][p0].x);
+            const T su = qfrom<li, LN>(sup);
+            const T alq = qfrom<li, LN>(hi == 0 ? a2[si][p0].y : a2[si][p0].x);
             T betaq, tq;
             const T scq = larfg_scale(alq, su, betaq, tq);
             e[i] = betaq;
             V2 u2[MP];
 #pragma unroll
-            for (int p = p0; p < MP; ++p) u2[p] = qbcast2<li>(a2[si][p]) * splat2(scq);
+            for (int p = p0; p < MP; ++p) u2[p] = qbcast2<li, LN>(a2[si][p]) * splat2(scq);
             if constexpr (hi == 0) u2[p0] = V2{T(0), T(1)};
             else u2[p0].x = T(1);
 #pragma unroll
@@ -247,7 +286,7 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, YF&& yget,
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int k = 2 * j + t;
-                h[t] = (k < K) ? ((4 * s + lq == M + k) ? T(1) : T(0)) : ((k == K) ? pick4<T, M>(z, 4 * s, lq) : T(0));
+                h[t] = (k < K) ? ((LN * s + lq == M + k) ? T(1) : T(0)) : ((k == K) ? pick4<T, M, LN>(z, LN * s, lq) : T(0));
             }
             nx[s][j] = V2{h[0], h[1]};
         }
@@ -255,7 +294,7 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, YF&& yget,
     // ---- [nb | x] <- G(1) ... G(M) [nb | x]
     static_for<0, M>([&](auto kc) {
         constexpr int i = M - 1 - decltype(kc)::value;
-        constexpr int si = i / 4;
+        constexpr int si = i / LN;
         T vrow[S];
 #pragma unroll
         for (int s = si; s < S; ++s) vrow[s] = a2[s][i / 2][i % 2];
@@ -269,7 +308,7 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, YF&& yget,
 #pragma unroll
                 for (int s = si + 1; s < S; ++s) w[j] = fma2(splat2(vrow[s]), nx[s][ja + j], w[j]);
             }
-            qsum_pairs<CNT, T>(w);
+            qsum_pairs<CNT, T, LN>(w);
 #pragma unroll
             for (int j = 0; j < CNT; ++j) {
                 w[j] *= splat2(taup[i]);
@@ -305,14 +344,14 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, YF&& yget,
 //     r >= t, a compile-time range: no used[] masks in the column scan or the arg-max, alpha[r] pairs with row r,
 //     and np.argmax's first-maximum tie-break is reproduced in the reference's own row order.
 // out[slot] = (Nc @ alpha)[4*slot + lq].
-template <typename T, int N, int K>
-__device__ __forceinline__ void rref_apply_quad_inl(T (&nb)[(N + 3) / 4][K], const T (&alpha)[K], T tol,
-                                                T (&out)[(N + 3) / 4], const int lq) {
-    constexpr int S = (N + 3) / 4;
+template <typename T, int N, int K, int LN>
+__device__ __forceinline__ void rref_apply_quad_inl(T (&nb)[(N + LN - 1) / LN][K], const T (&alpha)[K], T tol,
+                                                T (&out)[(N + LN - 1) / LN], const int lq) {
+    constexpr int S = (N + LN - 1) / LN;
     constexpr int BIG = 1 << 20;
     int col[S];
 #pragma unroll
-    for (int s = 0; s < S; ++s) col[s] = 4 * s + lq;
+    for (int s = 0; s < S; ++s) col[s] = LN * s + lq;
     int jrow[K];                       // column at which row r became a pivot row (BIG: never)
     int j0 = 0;
     static_for<0, K>([&](auto tc) {
@@ -328,7 +367,7 @@ __device__ __forceinline__ void rref_apply_quad_inl(T (&nb)[(N + 3) / 4][K], con
             cand = e ? col[s] : cand;
         }
         int jmin = min(cand, dpp_mov<0xB1>(cand));
-        jmin = min(jmin, dpp_mov<0x4E>(jmin));
+        if constexpr (LN == 4) jmin = min(jmin, dpp_mov<0x4E>(jmin));
         const bool found = jmin < BIG;
         // ---- that column's K entries, replicated over the quad (zeros when no column was found)
         T w[S];
@@ -340,7 +379,7 @@ __device__ __forceinline__ void rref_apply_quad_inl(T (&nb)[(N + 3) / 4][K], con
             T v = w[0] * nb[0][r];
 #pragma unroll
             for (int s = 1; s < S; ++s) v = num<T>::fma(w[s], nb[s][r], v);
-            f[r] = qsum(v);
+            f[r] = qsum<LN>(v);
         }
         // ---- pivot row: first arg-max of |f| over rows t..K-1 (np.argmax semantics in the reference's row order)
         T p = T(-1);
@@ -401,27 +440,27 @@ __device__ __forceinline__ void rref_apply_quad_inl(T (&nb)[(N + 3) / 4][K], con
 // is exact as float, as double with HOLD = true, and as double with either piece outlined) -- found by
 // tests/test_gpu_parity.py::test_refresh_and_exact_bias_variants_against_oracle.  Outlining keeps the double kernels
 // far from the register ceiling; their speed is irrelevant.
-template <typename T, int M, int N, typename AF, typename YF>
-__device__ __attribute__((noinline)) void bidiag_solve_null_quad_out(AF& aget, YF& yget, T (&x)[(N + 3) / 4],
-                                                                     T (&nb)[(N + 3) / 4][N - M], const int lq) {
-    bidiag_solve_null_quad_inl<T, M, N>(aget, yget, x, nb, lq);
+template <typename T, int M, int N, int LN, typename AF, typename YF>
+__device__ __attribute__((noinline)) void bidiag_solve_null_quad_out(AF& aget, YF& yget, T (&x)[(N + LN - 1) / LN],
+                                                                     T (&nb)[(N + LN - 1) / LN][N - M], const int lq) {
+    bidiag_solve_null_quad_inl<T, M, N, LN>(aget, yget, x, nb, lq);
 }
-template <typename T, int M, int N, typename AF, typename YF>
-__device__ __forceinline__ void bidiag_solve_null_quad(AF&& aget, YF&& yget, T (&x)[(N + 3) / 4],
-                                                       T (&nb)[(N + 3) / 4][N - M], const int lq) {
-    if constexpr (std::is_same<T, double>::value) bidiag_solve_null_quad_out<T, M, N>(aget, yget, x, nb, lq);
-    else bidiag_solve_null_quad_inl<T, M, N>(aget, yget, x, nb, lq);
+template <typename T, int M, int N, int LN = 4, typename AF, typename YF>
+__device__ __forceinline__ void bidiag_solve_null_quad(AF&& aget, YF&& yget, T (&x)[(N + LN - 1) / LN],
+                                                       T (&nb)[(N + LN - 1) / LN][N - M], const int lq) {
+    if constexpr (std::is_same<T, double>::value) bidiag_solve_null_quad_out<T, M, N, LN>(aget, yget, x, nb, lq);
+    else bidiag_solve_null_quad_inl<T, M, N, LN>(aget, yget, x, nb, lq);
 }
-template <typename T, int N, int K>
-__device__ __attribute__((noinline)) void rref_apply_quad_out(T (&nb)[(N + 3) / 4][K], const T (&alpha)[K], T tol,
-                                                              T (&out)[(N + 3) / 4], const int lq) {
-    rref_apply_quad_inl<T, N, K>(nb, alpha, tol, out, lq);
+template <typename T, int N, int K, int LN>
+__device__ __attribute__((noinline)) void rref_apply_quad_out(T (&nb)[(N + LN - 1) / LN][K], const T (&alpha)[K], T tol,
+                                                              T (&out)[(N + LN - 1) / LN], const int lq) {
+    rref_apply_quad_inl<T, N, K, LN>(nb, alpha, tol, out, lq);
 }
-template <typename T, int N, int K>
-__device__ __forceinline__ void rref_apply_quad(T (&nb)[(N + 3) / 4][K], const T (&alpha)[K], T tol,
-                                                T (&out)[(N + 3) / 4], const int lq) {
-    if constexpr (std::is_same<T, double>::value) rref_apply_quad_out<T, N, K>(nb, alpha, tol, out, lq);
-    else rref_apply_quad_inl<T, N, K>(nb, alpha, tol, out, lq);
+template <typename T, int N, int K, int LN = 4>
+__device__ __forceinline__ void rref_apply_quad(T (&nb)[(N + LN - 1) / LN][K], const T (&alpha)[K], T tol,
+                                                T (&out)[(N + LN - 1) / LN], const int lq) {
+    if constexpr (std::is_same<T, double>::value) rref_apply_quad_out<T, N, K, LN>(nb, alpha, tol, out, lq);
+    else rref_apply_quad_inl<T, N, K, LN>(nb, alpha, tol, out, lq);
 }
 
 }  // namespace atacom

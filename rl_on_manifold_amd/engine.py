@@ -62,7 +62,7 @@ class BatchedAtacomEnv:
             cfg.hold_q = int(bool(hold_q))
         cfg.bias_mode = {'reference': 0, 'exact': 1}[bias_mode]
         cfg.auto_reset = int(bool(auto_reset))
-        cfg.lanes_per_env = int(lanes_per_env)      # 0 auto, 1 lane-per-env, 4 quad-per-env kernels
+        cfg.lanes_per_env = int(lanes_per_env)      # 0 auto; 1, 2, 4 lanes per env (lane / pair / quad kernels)
         if term_tol is not None:
             cfg.term_tol = float(term_tol)
         cfg.random_init = int(bool(random_init))     # device-side random reset (circle_base.py:36-42, env_hitting.py:24-25)

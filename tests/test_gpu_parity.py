@@ -40,7 +40,7 @@ def _full_state(env, o):
     return full
 
 
-@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('lanes', [1, 2, 4])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 @pytest.mark.parametrize('name', ['circle', 'planar', 'iiwa'])
 def test_nullspace_against_reference_golden(golden, name, dt, lanes):
@@ -99,7 +99,7 @@ def test_constraint_terms_against_oracle(name, bias, dt):
     assert (J.cpu().numpy()[1:][(Jo == 0)[1:]] == 0).all()       # exact zeros of the oracle are exact on the device
 
 
-@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('lanes', [1, 2, 4])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 @pytest.mark.parametrize('name', ['circle', 'planar', 'iiwa'])
 def test_env_step_teacher_forced_against_oracle(name, dt, lanes):
@@ -135,7 +135,7 @@ def test_env_step_teacher_forced_against_oracle(name, dt, lanes):
     assert np.allclose(c_dev, c_or, atol=1e-8 if dt == 'f64' else 2e-3)
 
 
-@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('lanes', [1, 2, 4])
 @pytest.mark.parametrize('name', ['planar', 'iiwa'])
 def test_refresh_and_exact_bias_variants_against_oracle(name, lanes):
     """The two documented deviations-by-flag from the reference's quirks: hold_q = 0 (q, dq refreshed every sub-step
@@ -163,7 +163,7 @@ def test_refresh_and_exact_bias_variants_against_oracle(name, lanes):
     assert (env_d.step(a)[0] - env.step(a)[0]).abs().max() > 1e-6
 
 
-@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('lanes', [1, 2, 4])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 @pytest.mark.parametrize('name', ['planar', 'iiwa'])
 def test_puck_contact_model_against_oracle(name, dt, lanes):
@@ -255,7 +255,7 @@ def _policy_pair(golden, key, std=0.5, activation='relu'):
     return dev, ora
 
 
-@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('lanes', [1, 2, 4])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 @pytest.mark.parametrize('name,key', [('iiwa', 'ppo_iiwa'), ('planar', 'sac_planar')])
 def test_policy_rollout_against_oracle(golden, name, key, dt, lanes):
@@ -288,7 +288,7 @@ def test_policy_rollout_against_oracle(golden, name, key, dt, lanes):
         assert np.median(errs) < 5e-5 and (errs < 3e-3).mean() >= 0.98, (np.median(errs), (errs < 3e-3).mean())
 
 
-@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('lanes', [1, 2, 4])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 def test_sac_style_policy_rollout_against_oracle(golden, dt, lanes):
     """The reference's default agent is SAC (examples/iiwa_air_hockey_exp.py:345): mean and log-sigma networks
@@ -374,7 +374,7 @@ def test_circle_reference_trajectories_through_capi(golden, dt):
     assert np.allclose(logs, g['logs'][0], atol=1e-8 if dt == 'f64' else 5e-3), (logs, g['logs'][0])
 
 
-@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('lanes', [1, 2, 4])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 @pytest.mark.parametrize('name', ['planar', 'iiwa'])
 def test_generic_wrapper_reference_trajectories_through_capi(golden, name, dt, lanes):
@@ -404,7 +404,7 @@ def test_generic_wrapper_reference_trajectories_through_capi(golden, name, dt, l
         assert np.median(errs) < 5e-5 and (errs < 2e-3).mean() >= 0.98, (np.median(errs), (errs < 2e-3).mean())
 
 
-@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('lanes', [1, 2, 4])
 @pytest.mark.parametrize('name', ['circle', 'planar', 'iiwa'])
 def test_rollout_kernel_equals_step_kernel(name, lanes):
     """atacom_rollout (T steps, state in registers) == T x atacom_step (to a few ulp), incl. auto-reset."""
@@ -429,7 +429,7 @@ def test_rollout_kernel_equals_step_kernel(name, lanes):
     assert torch.equal(out['obs'][horizon], reset_obs)
 
 
-@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('lanes', [1, 2, 4])
 @pytest.mark.parametrize('B', [1, 63, 65])
 def test_ragged_batches_and_masked_reset(B, lanes):
     env = _env('iiwa', B, 'f32', lanes_per_env=lanes)
@@ -593,7 +593,7 @@ def test_device_random_init_matches_oracle_generator(name):
     assert not np.allclose(out['obs'][horizon].cpu().numpy()[:, :2], out['obs'][0].cpu().numpy()[:, :2])
 
 
-@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('lanes', [1, 2, 4])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 def test_chart_on_slack_structured_matrices(dt, lanes):
     """The chart (null basis + rref with the 0.05 tolerance) on J_c-shaped inputs [K J | diag(s)] with small and
@@ -632,14 +632,15 @@ def test_policy_rollout_matrix_core_path_ragged_batch(golden, name, key):
     gen = torch.Generator(device=DEV); gen.manual_seed(5)
     eps = torch.randn((T, B, k), device=DEV, generator=gen)
     outs, states = [], []
-    for lanes in (4, 1):
+    for lanes in (4, 2, 1):
         env = _env(name, B, 'f32', lanes_per_env=lanes, auto_reset=True, horizon=3, random_init=True, seed=11)
         outs.append(env.rollout_policy(dev, T, noise=eps))
         states.append(env.get_state())
-    a, b = outs
-    assert torch.equal(a['last'], b['last'])
-    assert torch.equal(states[0][:, -1], states[1][:, -1])               # step counters
-    for kk in ('obs', 'action', 'reward'):
-        err = (a[kk] - b[kk]).abs().reshape(T, B, -1).amax(-1)
-        assert float(err.median()) < 2e-5, kk
-        assert float((err < 5e-3).float().mean()) >= 0.97, kk           # the rest: rref tolerance flips
+    b = outs[-1]
+    for a, sa in zip(outs[:-1], states[:-1]):
+        assert torch.equal(a['last'], b['last'])
+        assert torch.equal(sa[:, -1], states[-1][:, -1])                  # step counters
+        for kk in ('obs', 'action', 'reward'):
+            err = (a[kk] - b[kk]).abs().reshape(T, B, -1).amax(-1)
+            assert float(err.median()) < 2e-5, kk
+            assert float((err < 5e-3).float().mean()) >= 0.97, kk       # the rest: rref tolerance flips
