@@ -1,4 +1,5 @@
-// Quad-cooperative variant of the null-space solver: FOUR LANES PER ENVIRONMENT.
+// Lane-group variant of the null-space solver: FOUR (a DPP quad) or TWO (a lane pair) LANES PER ENVIRONMENT.
+// (Written and described for the quad; the group size is the template parameter LN, see qbcast / qsum below.)
 //
 // Why (measured in profiles/): a wave64 vector instruction occupies its SIMD for 4 clocks and a
 // lone wave already saturates it, so the step time is (vector instructions per wave) x ~5 clk.  With one environment
