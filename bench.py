@@ -7,18 +7,32 @@ A "step" is ONE call of the hot path over one batch: `atacom_step` (C ABI, one H
 B = 8192 IiwaAirHockey-7H environments per GPU -- action clip/scale, 4 x [constraint Jacobians + FK,
 null-space projection, slack integration, truncation, dynamics], reward / termination / observation,
 constraint statistics, masked auto-reset at the horizon.  Inputs (actions) are resident in HBM before the
-timed region.  N > 1: one process per GPU (torchrun), each rank owns its own 8192-env shard (weak
-scaling, no collective on the data path); time = max over ranks between two barriers.
+timed region.
+
+N > 1: one process per GPU over RCCL.  `python bench.py --gpus N` spawns the N ranks itself (it re-executes
+under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`); launched under
+torchrun by someone else it uses the ranks it was given (and refuses a WORLD_SIZE that contradicts --gpus).
+Each rank owns its own 8192-env shard (weak scaling, no collective on the data path).
+
+Timing: W warm-up steps, then BLOCKS of exactly K steps, each bracketed by barrier + synchronize on both sides,
+each block's time = MAX over ranks; blocks are repeated until >= --min-time seconds have been timed and the MEDIAN
+block is reported (a single 20-step block is 0.6 ms -- one scheduler hiccup would move the number by 10 %).
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      HBM view: algorithmic bytes per launch / mean kernel time (HIP events on the launch stream)
   roofline_valu fp32 vector-ALU view of the same kernel (this workload is ALU/latency bound)
-  cpu_baseline  the float64 oracle in the reference's algorithmic shape (one SVD + RREF per env per
-                sub-step), timed on this box's host cores on a bounded sample (rank 0, N = 1 only)
+  collection    config 5's collection phase: rollout_packed(120 steps, one launch) + the one all-gather of the
+                packed records (ms, bytes, GB/s per rank)
+  secondary     circle-4096 and planar-8192 (BASELINE configs 2 and 3) with their own rooflines (N = 1 only)
+  cpu_baseline  the float64 oracle timed on this box's host cores on bounded samples (rank 0, N = 1 only):
+                scalar reference-shaped (1 core and all cores) and batched numpy; + the oracle's constraint
+                statistics on 256 of the very same initial states and actions next to the device's
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,6 +46,8 @@ VALU_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
 # derivation in DESIGN.md "Measurement"): state read once + written once, action in, obs/reward/flags out.
 ALGO_BYTES = {'circle': 60, 'planar': 220, 'iiwa': 400}
 SHAPES = {'circle': (2, 3, 1, 2, 1), 'planar': (6, 9, 3, 3, 4), 'iiwa': (12, 17, 5, 6, 4)}   # c, n, k, nq, substeps
+WORKLOAD = {'iiwa': 'IiwaAirHockey env 7H', 'planar': 'PlanarAirHockey env H', 'circle': 'CircularMotion env A'}
+IIWA_INIT_Q = [0.0, 0.7135214629060707, 0.0, -0.5024756033561426, 0.0, 1.9256631778550268]
 
 
 def algorithmic_flops(env):
@@ -56,6 +72,138 @@ def algorithmic_flops(env):
     return sub * per_sub + 2 * fk + 4 * M * nq
 
 
+# ------------------------------------------------------------------------------------------ rank spawning
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: re-execute under torch.distributed.run, one rank per GPU."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % n,
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------ synthetic data
+def feasible_init(name, B, dev, gen, sigma=0.05):
+    """Initial joint states per SURVEY.md section 8d (configs 3 / 4): q = q_init + N(0, sigma^2), one Newton correction
+    step onto the equality constraint (iiwa: tip height z_ee = 0.1505), REJECTED unless every inequality g < 0 and
+    |f| < 1e-3 afterwards; dq = 0; puck uniform in the hit range (env_hitting.py:11,24-25).  The constraint values
+    come from the library's own `atacom_constraint_terms` primitive (C ABI) -- no oracle here.
+    Returns ([B, init_state_dim] rows for reset(state=...), fraction of draws rejected)."""
+    import torch
+    from rl_on_manifold_amd import constraint_terms
+    nq, nf = {'planar': (3, 0), 'iiwa': (6, 1)}[name]
+    q0 = torch.tensor({'planar': [-0.9273, 0.9273, 3.141592653589793 / 2], 'iiwa': IIWA_INIT_Q}[name],
+                      device=dev, dtype=torch.float32)
+    keep, drawn = [], 0
+    while sum(k.shape[0] for k in keep) < B:
+        n = max(B // 2, 1024)
+        q = q0 + sigma * torch.randn((n, nq), device=dev, generator=gen)
+        dq = torch.zeros_like(q)
+        if nf:
+            fun, J, _ = constraint_terms(name, q, dq)
+            Jf = J[:, 0, :]
+            q = q - Jf * (fun[:, :1] / (Jf * Jf).sum(1, keepdim=True))       # one correction step
+        fun, _, _ = constraint_terms(name, q, dq)
+        ok = (fun[:, nf:] < 0).all(1)
+        if nf:
+            ok &= fun[:, 0].abs() < 1e-3
+        keep.append(q[ok])
+        drawn += n
+    q = torch.cat(keep)[:B]
+    kept_of = sum(k.shape[0] for k in keep)
+    init = torch.zeros((B, 2 * nq + 6), device=dev)
+    init[:, :nq] = q
+    init[:, 2 * nq + 0] = -0.6 + 0.4 * torch.rand((B,), device=dev, generator=gen)
+    init[:, 2 * nq + 1] = -0.4 + 0.8 * torch.rand((B,), device=dev, generator=gen)
+    return init, 1.0 - kept_of / drawn
+
+
+def make_env(name, B, dev, gen, lanes=0):
+    import torch
+    from rl_on_manifold_amd import BatchedAtacomEnv
+    env = BatchedAtacomEnv(name, B, device=dev, dtype=torch.float32, auto_reset=True, lanes_per_env=lanes)
+    init, rej = None, 0.0
+    if name != 'circle':
+        init, rej = feasible_init(name, B, dev, gen)
+        env.reset(state=init)
+    else:
+        # SURVEY.md section 8d config 2: half at the reference's fixed reset point, half random valid states
+        # (circle_base.py:36-42: a point on the circle above y = -0.5 with a tangential velocity)
+        st = torch.zeros((B, 4), device=dev)
+        st[:, 0] = -1.0
+        h = B // 2
+        y = -0.5 + 1.5 * torch.rand((h,), device=dev, generator=gen)
+        sg = torch.where(torch.rand((h,), device=dev, generator=gen) < 0.5, -1.0, 1.0)
+        x = torch.sqrt((1 - y * y).clamp_min(0)) * sg
+        sp = torch.rand((h,), device=dev, generator=gen) * torch.where(torch.rand((h,), device=dev, generator=gen) < 0.5, -1.0, 1.0)
+        st[:h, 0], st[:h, 1], st[:h, 2], st[:h, 3] = x, y, -y * sp, x * sp
+        init = st
+        env.reset(state=st)
+    return env, init, rej
+
+
+# ------------------------------------------------------------------------------------------ the timed loop
+def time_steps(env, actions, K, W, min_time, sync_all, max_over_ranks, max_blocks=20000):
+    """W warm-up steps, then blocks of exactly K atacom_step launches; returns (per-block seconds [max over ranks],
+    mean kernel ms from HIP events on the launch stream over all timed launches)."""
+    import numpy as np
+    import torch
+    B, D = env.batch, env.obs_dim
+    dev = env.device
+    obs = torch.empty((B, D), device=dev)
+    rew = torch.empty((B,), device=dev)
+    ab = torch.empty((B,), device=dev, dtype=torch.uint8)
+    last = torch.empty((B,), device=dev, dtype=torch.uint8)
+    n_pool = actions.shape[0]
+    it = 0
+    for _ in range(W):
+        env.step_into(actions[it % n_pool], obs, rew, ab, last)
+        it += 1
+
+    def block():
+        nonlocal it
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync_all()                                   # barrier + synchronize
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(K):
+            env.step_into(actions[it % n_pool], obs, rew, ab, last)
+            it += 1
+        e1.record()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        sync_all()                                   # barrier + synchronize on the far side too
+        return dt, e0.elapsed_time(e1)
+
+    first = block()
+    # every rank must run the same number of blocks: decide it from the first block's max-over-ranks time
+    t_first = max_over_ranks([first[0]])[0]
+    n_blocks = int(min(max(3, min_time / max(t_first, 1e-9)), max_blocks))
+    res = [first] + [block() for _ in range(n_blocks - 1)]
+    secs = max_over_ranks([r[0] for r in res])
+    kern_ms = float(np.mean([r[1] for r in res])) / K
+    return secs, kern_ms
+
+
+def roofline_objects(name, B, kern_ms, traffic=None):
+    algo_bytes = ALGO_BYTES[name] * B
+    flops = algorithmic_flops(name) * B
+    gbs = algo_bytes / (kern_ms * 1e-3) / 1e9
+    tf = flops / (kern_ms * 1e-3) / 1e12
+    return ({'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+             'traffic': traffic, 'algorithmic_bytes_per_launch': algo_bytes, 'kernel_ms': kern_ms,
+             'note': 'workload is fp32-VALU / dependent-issue bound, see roofline_valu and DESIGN.md'},
+            {'bound': 'valu_f32', 'achieved': tf, 'peak': VALU_F32_PEAK_TF, 'unit': 'TFLOP/s',
+             'frac': tf / VALU_F32_PEAK_TF, 'algorithmic_flops_per_launch': flops})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -63,125 +211,126 @@ def main():
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--env', default='iiwa')
     ap.add_argument('--batch', type=int, default=8192)
-    ap.add_argument('--lanes', type=int, default=0, help='kernel mapping: 0 = library policy, 1 = env per lane, 4 = env per quad')
+    ap.add_argument('--lanes', type=int, default=0, help='kernel mapping: 0 = library policy, else lanes per env')
+    ap.add_argument('--min-time', type=float, default=0.5, help='keep timing K-step blocks until this many seconds')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=12.0)
+    ap.add_argument('--no-secondary', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=8.0, help='budget of each scalar CPU-baseline leg')
     args = ap.parse_args()
+
+    env_world = os.environ.get('WORLD_SIZE')
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    world = int(env_world or '1')
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d contradicts WORLD_SIZE=%d of the launcher' % (args.gpus, world))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
 
     import numpy as np
     import torch
     import torch.distributed as dist
-    from rl_on_manifold_amd import BatchedAtacomEnv
+    from rl_on_manifold_amd import MlpPolicy
+    from rl_on_manifold_amd.rollout import RolloutCollector
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     # BENCH_DIST_BACKEND=gloo lets the multi-rank control flow be exercised on a box with fewer GPUs than ranks
     # (ranks then share devices); the driver's runs use the default, nccl (= RCCL), one rank per GPU.
     backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
-    dev = torch.device('cuda', local_rank % max(torch.cuda.device_count(), 1))
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        sys.exit('bench.py: no ROCm GPU visible (the engine has no CPU path)')
+    if backend == 'nccl' and world > n_dev:
+        sys.exit('bench.py: --gpus %d but only %d GPU(s) visible; RCCL needs one GPU per rank '
+                 '(BENCH_DIST_BACKEND=gloo exercises the multi-rank control flow on fewer GPUs)' % (world, n_dev))
+    dev = torch.device('cuda', local_rank % n_dev)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        kw = {'device_id': dev} if backend == 'nccl' else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     red_dev = dev if backend == 'nccl' else torch.device('cpu')
 
-    B, K, W = args.batch, args.steps, args.warmup
-    env = BatchedAtacomEnv(args.env, B, device=dev, dtype=torch.float32, auto_reset=True, lanes_per_env=args.lanes)
-    k, D = env.dims['null'], env.obs_dim
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    # synthetic data: per-env random initial joint states around the reset pose + a pool of pre-generated actions
-    st = env.get_state()
-    nq = env.dims['q']
-    if args.env != 'circle':
-        init = torch.zeros((B, env.init_state_dim), device=dev)
-        init[:, :nq] = st[:, :nq] + 0.05 * torch.randn((B, nq), device=dev, generator=gen)
-        init[:, 2 * nq:] = st[:, 2 * nq + env.dims['g']: 2 * nq + env.dims['g'] + 6]
-        env.reset(state=init)
-    n_pool = 64
-    actions = torch.rand((n_pool, B, k), device=dev, generator=gen) * 2 - 1
-    obs = torch.empty((B, D), device=dev)
-    rew = torch.empty((B,), device=dev)
-    ab = torch.empty((B,), device=dev, dtype=torch.uint8)
-    last = torch.empty((B,), device=dev, dtype=torch.uint8)
-
     def sync_all():
+        torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(W):
-        env.step_into(actions[i % n_pool], obs, rew, ab, last)
-    sync_all()
-    # ---- timed region: exactly K steps, bracketed by barrier + synchronize on both sides; two HIP events on the
-    # launch stream bracket the same K launches (the queue never drains, so events/K = mean launch duration
-    # including the ~1-2 us inter-kernel gap)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for i in range(K):
-        env.step_into(actions[i % n_pool], obs, rew, ab, last)
-    e1.record()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    kern_ms = e0.elapsed_time(e1) / K
-    # isolated per-launch durations (event pair around each launch, outside the timed region)
-    n_iso = min(K, 200)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_iso)]
-    for i in range(n_iso):
-        ev[i][0].record()
-        env.step_into(actions[i % n_pool], obs, rew, ab, last)
-        ev[i][1].record()
-    torch.cuda.synchronize(dev)
-    kern_ms_iso = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    def max_over_ranks(vals):
+        if world == 1:
+            return list(vals)
+        t = torch.tensor(list(vals), device=red_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.cpu().tolist()
+
+    B, K, W = args.batch, args.steps, args.warmup
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    env, init, rejected = make_env(args.env, B, dev, gen, args.lanes)
+    k, D = env.dims['null'], env.obs_dim
+    n_pool = 64
+    actions = torch.rand((n_pool, B, k), device=dev, generator=gen) * 2 - 1
+
+    # ---- headline: blocks of exactly K steps
+    secs, kern_ms = time_steps(env, actions, K, W, args.min_time, sync_all, max_over_ranks)
+    elapsed = float(np.median(secs))
     c_avg, c_max, c_dq_max = env.get_constraints_logs()
     if world > 1:
-        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        cm = torch.tensor([c_max, c_dq_max], device=red_dev, dtype=torch.float64)
-        dist.all_reduce(cm, op=dist.ReduceOp.MAX)
-        c_max, c_dq_max = float(cm[0].item()), float(cm[1].item())
+        c_max, c_dq_max = max_over_ranks([c_max, c_dq_max])
 
-    # ---- secondary: the same K steps as launches of the multi-step rollout kernel (120 steps per launch)
+    # ---- collection phase of config 5: 120-step rollout (one launch, packed records) + the one all-gather
     T = 120
+    col = RolloutCollector(env)
     racts = torch.rand((T, B, k), device=dev, generator=gen) * 2 - 1
-    out = env.rollout(racts)
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    n_roll = max(1, K // T)
-    for _ in range(n_roll):
-        env.rollout(racts, out=out)
-    torch.cuda.synchronize(dev)
-    roll_rate = n_roll * T * B / (time.perf_counter() - t1)
-
-    # ---- secondary (row N2): the same rollout with the actor MLP (18-64-64-5, random weights) + Gaussian noise
-    # evaluated inside the kernel -- one launch per 120-step collection phase, no per-step host round trip
-    pol_rate = None
-    if args.env != 'circle':
-        from rl_on_manifold_amd import MlpPolicy
-        gw = torch.Generator(device='cpu'); gw.manual_seed(0)
-        Wts = [torch.randn(64, D, generator=gw) * 0.2, torch.zeros(64), torch.randn(64, 64, generator=gw) * 0.1,
-             torch.zeros(64), torch.randn(k, 64, generator=gw) * 0.1, torch.zeros(k)]
-        pol = MlpPolicy(*Wts, std=torch.full((k,), 0.5))
-        eps = torch.randn((T, B, k), device=dev, generator=gen)
-        env.rollout_policy(pol, T, noise=eps)
+    rec = env.rollout_packed(actions=racts)
+    gathered = col.gather(rec)
+    sync_all()
+    n_rep = 5
+    t_roll, t_gath = [], []
+    for _ in range(n_rep):
+        sync_all()
+        t0 = time.perf_counter()
+        env.rollout_packed(actions=racts, out=rec)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        gathered = col.gather(rec)
         torch.cuda.synchronize(dev)
         t2 = time.perf_counter()
-        for _ in range(n_roll):
-            env.rollout_policy(pol, T, noise=eps)
+        t_roll.append(t1 - t0)
+        t_gath.append(t2 - t1)
+    t_roll = float(np.median(max_over_ranks(t_roll)))
+    t_gath = float(np.median(max_over_ranks(t_gath)))
+    sent = rec.numel() * rec.element_size()
+    recv = gathered.numel() * gathered.element_size()
+    collection = {'steps': T, 'records': list(gathered.shape), 'rollout_ms': t_roll * 1e3,
+                  'rollout_env_steps_per_s_per_gpu': B * T / t_roll,
+                  'allgather_ms': t_gath * 1e3 if world > 1 else None,
+                  'bytes_sent_per_rank': sent, 'bytes_received_per_rank': recv if world > 1 else 0,
+                  'allgather_GBps_per_rank': (recv - sent) / t_gath / 1e9 if world > 1 else None,
+                  'collection_env_steps_per_s': world * B * T / (t_roll + (t_gath if world > 1 else 0.0)),
+                  'backend': backend if world > 1 else None}
+    del gathered
+
+    # ---- the same collection with the actor MLP (18-64-64-5, random weights) + Gaussian noise inside the kernel (row N2)
+    pol_rate = None
+    if args.env != 'circle':
+        gw = torch.Generator(device='cpu'); gw.manual_seed(0)
+        Wts = [torch.randn(64, D, generator=gw) * 0.2, torch.zeros(64), torch.randn(64, 64, generator=gw) * 0.1,
+               torch.zeros(64), torch.randn(k, 64, generator=gw) * 0.1, torch.zeros(k)]
+        pol = MlpPolicy(*Wts, std=torch.full((k,), 0.5))
+        eps = torch.randn((T, B, k), device=dev, generator=gen)
+        env.rollout_packed(policy=pol, n_steps=T, noise=eps, out=rec)
         torch.cuda.synchronize(dev)
-        pol_rate = n_roll * T * B / (time.perf_counter() - t2)
+        t2 = time.perf_counter()
+        for _ in range(n_rep):
+            env.rollout_packed(policy=pol, n_steps=T, noise=eps, out=rec)
+        torch.cuda.synchronize(dev)
+        pol_rate = n_rep * T * B / (time.perf_counter() - t2)
+    env.get_constraints_logs()
 
     result = None
     if rank == 0:
-        value = world * B * K / elapsed
-        algo_bytes = ALGO_BYTES[args.env] * B
-        flops = algorithmic_flops(args.env) * B
-        achieved_gbs = algo_bytes / (kern_ms * 1e-3) / 1e9
-        achieved_tf = flops / (kern_ms * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.env)
         if os.path.exists(tpath):
@@ -189,29 +338,34 @@ def main():
                 traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
             except Exception:  # noqa: BLE001
                 traffic = None
+        roof, roof_valu = roofline_objects(args.env, B, kern_ms, traffic)
         result = {
-            'metric': 'env-steps/sec', 'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K,
-            'warmup': W, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'metric': 'env-steps/sec', 'value': world * B * K / elapsed, 'unit': 'env-steps/s', 'n_gpus': world,
+            'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': {'iiwa': 'IiwaAirHockey env 7H', 'planar': 'PlanarAirHockey env H',
-                                    'circle': 'CircularMotion env A'}[args.env] + ', batch %d per GPU' % B,
-                       'batch_per_gpu': B, 'global_batch': B * world, 'lanes_per_env_requested': int(env.cfg.lanes_per_env), 'substeps': int(env.cfg.substeps),
+            'config': {'workload': WORKLOAD[args.env] + ', batch %d per GPU' % B,
+                       'batch_per_gpu': B, 'global_batch': B * world,
+                       'lanes_per_env_requested': int(env.cfg.lanes_per_env), 'substeps': int(env.cfg.substeps),
                        'horizon': int(env.cfg.horizon), 'path': 'atacom_step (1 launch / step) via C ABI',
+                       'init': 'q_init + N(0, 0.05^2), one correction step, rejected unless all g < 0 and |f| < 1e-3 '
+                               '(%.1f %% of draws rejected); puck uniform in the hit range' % (100 * rejected)
+                               if args.env != 'circle' else 'half fixed reset point, half random valid states',
                        'parallelism': 'env-shard x%d, no data-path collective' % world},
+            'timing': {'blocks': len(secs), 'block_steps': K, 'block_ms_median': elapsed * 1e3,
+                       'block_ms_min': min(secs) * 1e3, 'block_ms_max': max(secs) * 1e3,
+                       'timed_seconds_total': float(sum(secs)), 'statistic': 'median over blocks of (max over ranks)'},
             'max_abs_c': c_max, 'c_avg': c_avg, 'c_dq_max': c_dq_max,
-            'rollout_kernel_env_steps_per_s_per_gpu': roll_rate,
+            'collection': collection,
             'policy_rollout_kernel_env_steps_per_s_per_gpu': pol_rate,
-            'roofline': {'bound': 'hbm', 'achieved': achieved_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved_gbs / HBM_PEAK_GBS, 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': algo_bytes, 'kernel_ms': kern_ms,
-                         'kernel_ms_isolated_median': kern_ms_iso,
-                         'note': 'workload is fp32-VALU / latency bound, see roofline_valu and DESIGN.md'},
-            'roofline_valu': {'bound': 'valu_f32', 'achieved': achieved_tf, 'peak': VALU_F32_PEAK_TF,
-                              'unit': 'TFLOP/s', 'frac': achieved_tf / VALU_F32_PEAK_TF,
-                              'algorithmic_flops_per_launch': flops},
+            'roofline': roof, 'roofline_valu': roof_valu,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(args.env, args.cpu_seconds)
+    # the engine of the headline run is no longer needed; secondary workloads and the CPU legs are N = 1 extras
+    if world == 1 and rank == 0:
+        if not args.no_secondary and args.env == 'iiwa' and args.batch == 8192:
+            result['secondary'] = secondary_records(dev, gen, K, W, sync_all, max_over_ranks)
+        if not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(args.env, args.cpu_seconds, dev, init, k)
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
@@ -219,28 +373,81 @@ def main():
     return result
 
 
-def cpu_baseline(env_name, budget_s):
-    """The oracle as the CPU baseline ("port"): float64, reference algorithmic shape -- one LAPACK SVD and one
-    RREF per environment per physics sub-step, one environment at a time, one core."""
+def secondary_records(dev, gen, K, W, sync_all, max_over_ranks):
+    """BASELINE configs 2 and 3 (circle A batch 4096, planar H batch 8192): same timing protocol, shorter."""
     import numpy as np
-    from oracle import atacom_scalar as osc
-    spec = {'circle': osc.circle_spec, 'planar': osc.planar_spec, 'iiwa': osc.iiwa_spec}[env_name]()
-    init_q = None
-    if env_name == 'iiwa':
-        init_q = np.array([0.0, 0.7135214629060707, 0.0, -0.5024756033561426, 0.0, 1.9256631778550268])
-    rng = np.random.default_rng(0)
-    env = osc.ScalarAtacomEnv(spec, init_q=init_q)
-    n = 0
+    import torch
+    out = []
+    for name, B in (('circle', 4096), ('planar', 8192)):
+        env, _, _ = make_env(name, B, dev, gen)
+        k = env.dims['null']
+        acts = torch.rand((64, B, k), device=dev, generator=gen) * 2 - 1
+        secs, kern_ms = time_steps(env, acts, K, W, 0.2, sync_all, max_over_ranks)
+        el = float(np.median(secs))
+        c_avg, c_max, c_dq = env.get_constraints_logs()
+        racts = torch.rand((120, B, k), device=dev, generator=gen) * 2 - 1
+        rec = env.rollout_packed(actions=racts)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            env.rollout_packed(actions=racts, out=rec)
+        torch.cuda.synchronize(dev)
+        roll = 5 * 120 * B / (time.perf_counter() - t0)
+        roof, roof_valu = roofline_objects(name, B, kern_ms)
+        out.append({'workload': WORKLOAD[name] + ', batch %d' % B, 'value': B * K / el, 'unit': 'env-steps/s',
+                    'ms_per_step': el / K * 1e3, 'blocks': len(secs), 'max_abs_c': c_max, 'c_avg': c_avg,
+                    'c_dq_max': c_dq, 'rollout_kernel_env_steps_per_s': roll, 'roofline': roof,
+                    'roofline_valu': roof_valu})
+        env.close()
+    return out
+
+
+def cpu_baseline(env_name, budget_s, dev, init, k):
+    """The oracle as the CPU baseline ("port"; the reference itself needs Pinocchio / PyBullet / MushroomRL and never
+    travels to this box).  Three legs on the host cores of the GPU box:
+      R1  scalar, reference algorithmic shape (one LAPACK SVD + one RREF per environment per sub-step), 1 core;
+      R1' the same on all cores (independent processes, core count stated);
+      R2  batched numpy restatement, 1 process -- run on 256 of the bench's own initial states with a fixed action
+          sequence, which also yields the oracle's constraint statistics next to the device's on identical input."""
+    import multiprocessing as mp
+    import numpy as np
+    import torch
+    from oracle import cpu_legs
+    from rl_on_manifold_amd import BatchedAtacomEnv
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    one = cpu_legs.scalar_leg((env_name, budget_s, 0))
+    ctx = mp.get_context('spawn')
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        for _ in range(8):
-            env.step(rng.uniform(-1, 1, spec.n_null))
-            n += 1
-            if env.t >= spec.horizon:
-                env.reset()
-    dt = time.perf_counter() - t0
-    return {'value': n / dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
-            'sample': '%d sequential env-steps of one %s env (float64 numpy/scipy oracle, %.1f s)' % (n, env_name, dt),
+    with ctx.Pool(cores) as pool:
+        parts = pool.map(cpu_legs.scalar_leg, [(env_name, budget_s, i + 1) for i in range(cores)])
+    wall_all = time.perf_counter() - t0
+    all_rate = sum(p['steps'] / p['seconds'] for p in parts)
+    # ---- R2 + constraint check on identical states / actions
+    n_sub, T = 256, 120
+    rng = np.random.default_rng(5)
+    acts = rng.uniform(-1, 1, (T, n_sub, k))
+    sub_init = None if init is None else init[:n_sub].double().cpu().numpy()
+    t0 = time.perf_counter()
+    ora = cpu_legs.batched_leg(env_name, sub_init, acts)
+    dt_b = time.perf_counter() - t0
+    denv = BatchedAtacomEnv(env_name, n_sub, device=dev, dtype=torch.float32, auto_reset=True)
+    if init is not None:
+        denv.reset(state=init[:n_sub])
+    denv.rollout(torch.as_tensor(acts, dtype=torch.float32, device=dev))
+    d_avg, d_max, d_dq = denv.get_constraints_logs()
+    denv.close()
+    return {'value': all_rate, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': 'float64 numpy/scipy oracle in the reference\'s algorithmic shape (SVD + RREF per env per sub-step), '
+                      '%d independent processes x %.0f s of sequential %s env-steps (%.1f s wall incl. process start)'
+                      % (cores, budget_s, env_name, wall_all),
+            'legs': {'scalar_1_core': {'value': one['steps'] / one['seconds'], 'cores': 1, 'steps': one['steps']},
+                     'scalar_all_cores': {'value': all_rate, 'cores': cores, 'steps': int(sum(p['steps'] for p in parts))},
+                     'batched_numpy': {'value': n_sub * T / dt_b, 'cores': 1, 'steps': n_sub * T,
+                                       'blas_threads': os.environ.get('OMP_NUM_THREADS', 'default')}},
+            'constraint_check': {'envs': n_sub, 'steps': T, 'note': 'same initial states and actions, free-running',
+                                 'oracle_f64': {'c_avg': ora['c_avg'], 'c_max': ora['c_max'], 'c_dq_max': ora['c_dq_max']},
+                                 'device_f32': {'c_avg': d_avg, 'c_max': d_max, 'c_dq_max': d_dq},
+                                 'c_max_ratio_device_over_oracle': d_max / ora['c_max'] if ora['c_max'] else None},
             'host_cpus_visible': os.cpu_count()}
 
 

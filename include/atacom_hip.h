@@ -92,6 +92,7 @@ typedef struct atacom_dims {
     int32_t state_dim;      /* floats per env in atacom_get_state / atacom_set_state:
                                [q, dq, s, puck(6), has_hit, r_hit, vel_hit_x, t] */
     int32_t init_state_dim; /* floats per env in atacom_reset's d_init_state: [q, dq] (+ puck(6) for planar/iiwa) */
+    int32_t record_dim;     /* floats per (step, env) record of atacom_rollout_packed: 2 obs_dim + n_null + 3 */
 } atacom_dims;
 
 int atacom_default_config(int32_t env_id, atacom_config* out);
@@ -151,6 +152,18 @@ typedef struct atacom_mlp {
 int atacom_rollout_mlp(atacom_handle* h, int32_t n_steps, const atacom_mlp* net, const void* d_noise, void* d_obs,
                        void* d_next_obs, void* d_actions, void* d_reward, uint8_t* d_absorbing, uint8_t* d_last,
                        void* stream);
+
+/* The same rollouts writing ONE packed float record per (step, env) instead of six arrays:
+ *   d_records [n_steps, record_batch_stride, record_dim],
+ *   record = [obs(obs_dim) | action(n_null) | reward | next_obs(obs_dim) | absorbing (0/1) | last (0/1)]
+ * -- the (s, a, r, s', absorbing, last) tuple of mushroom_rl.Core's dataset (what examples/circle_exp.py:72
+ * `core.learn(...)` hands to agent.fit), laid out so that a sharded collector can all-gather the buffer as it is
+ * (rl_on_manifold_amd/rollout.py: one collective, no repacking pass).  Exactly one of d_actions
+ * ([n_steps, batch, n_null], pre-generated actions as in atacom_rollout) and net (policy evaluated in the kernel as in
+ * atacom_rollout_mlp, with d_noise) must be given.  record_batch_stride >= batch lets ragged shards share one padded
+ * buffer shape; rows batch..stride-1 are not written. */
+int atacom_rollout_packed(atacom_handle* h, int32_t n_steps, const void* d_actions, const atacom_mlp* net,
+                          const void* d_noise, void* d_records, int32_t record_batch_stride, void* stream);
 
 /* get_constraints_logs (atacom.py:207-216; circle_base.py:109-115): out = {c_avg, c_max, c_dq_max} over every
  * (env, step) logged since the last clear.  Synchronises `stream`. */

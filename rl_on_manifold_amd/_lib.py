@@ -14,7 +14,7 @@ ENV_CIRCLE, ENV_PLANAR, ENV_IIWA, ENV_CIRCLE_EC, ENV_CIRCLE_T = 0, 1, 2, 3, 4
 F32, F64 = 0, 1
 MAX_C, MAX_Q = 12, 6
 
-EXPORTS = ['atacom_rollout_mlp', 'atacom_default_config', 'atacom_get_dims', 'atacom_create', 'atacom_destroy', 'atacom_reset',
+EXPORTS = ['atacom_rollout_mlp', 'atacom_rollout_packed', 'atacom_default_config', 'atacom_get_dims', 'atacom_create', 'atacom_destroy', 'atacom_reset',
            'atacom_step', 'atacom_rollout', 'atacom_get_stats', 'atacom_get_state', 'atacom_set_state',
            'atacom_nullspace', 'atacom_constraint_terms', 'atacom_last_error', 'atacom_version']
 
@@ -44,7 +44,8 @@ class AtacomMlp(C.Structure):
 
 class AtacomDims(C.Structure):
     _fields_ = [('dim_q', C.c_int32), ('n_f', C.c_int32), ('n_g', C.c_int32), ('n_null', C.c_int32),
-                ('obs_dim', C.c_int32), ('state_dim', C.c_int32), ('init_state_dim', C.c_int32)]
+                ('obs_dim', C.c_int32), ('state_dim', C.c_int32), ('init_state_dim', C.c_int32),
+                ('record_dim', C.c_int32)]
 
 
 class AtacomError(RuntimeError):
@@ -79,6 +80,7 @@ def load():
     lib.atacom_step.argtypes = [vp, vp, vp, vp, u8p, u8p, vp]
     lib.atacom_rollout.argtypes = [vp, i32, vp, vp, vp, vp, u8p, u8p, vp]
     lib.atacom_rollout_mlp.argtypes = [vp, i32, C.POINTER(AtacomMlp), vp, vp, vp, vp, vp, u8p, u8p, vp]
+    lib.atacom_rollout_packed.argtypes = [vp, i32, vp, C.POINTER(AtacomMlp), vp, vp, i32, vp]
     lib.atacom_get_stats.argtypes = [vp, C.POINTER(C.c_double * 3), i32, vp]
     lib.atacom_get_state.argtypes = [vp, vp, vp]
     lib.atacom_set_state.argtypes = [vp, vp, vp]

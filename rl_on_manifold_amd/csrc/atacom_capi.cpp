@@ -26,6 +26,26 @@ int fail(int code, const std::string& msg) {
             return fail(ATACOM_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
     } while (0)
 
+// Every entry point that touches a handle runs on the handle's device and puts the caller's current device back on
+// the way out (a handle on cuda:1 must not leave the calling thread -- i.e. PyTorch -- on cuda:1).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        err = (prev == dev) ? hipSuccess : hipSetDevice(dev);
+        if (prev == dev) prev = -1;               // nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define ON_DEVICE(h)                \
+    DeviceGuard guard_((h)->device); \
+    HIP_TRY(guard_.err)
+
 const atacom::EnvOps* get_ops(int env_id, int dtype) {
     if (dtype != ATACOM_F32 && dtype != ATACOM_F64) return nullptr;
     switch (env_id) {
@@ -69,6 +89,9 @@ void default_init_row(int env_id, std::vector<double>& row) {
 
 }  // namespace
 
+struct atacom_handle;
+static int check_mlp(const atacom_handle* h, const atacom_mlp* net, const char* who);
+
 struct atacom_handle {
     atacom_config cfg;
     int device;
@@ -78,6 +101,23 @@ struct atacom_handle {
     double* partial_dev;
     double* partial_host;
 };
+
+static int check_mlp(const atacom_handle* h, const atacom_mlp* net, const char* who) {
+    const std::string w(who);
+    if (net->struct_size != (int32_t)sizeof(atacom_mlp))
+        return fail(ATACOM_E_INVALID, w + ": atacom_mlp.struct_size mismatch (ABI)");
+    if (net->n_in != h->ops->obs_dim || net->n_out != h->ops->nk)
+        return fail(ATACOM_E_INVALID, w + ": network n_in / n_out must equal obs_dim / n_null");
+    if (!net->W1 || !net->b1 || !net->W2 || !net->b2 || !net->W3 || !net->b3)
+        return fail(ATACOM_E_INVALID, w + ": null weight pointer");
+    const int n_sig = (net->sW1 != nullptr) + (net->sb1 != nullptr) + (net->sW2 != nullptr) + (net->sb2 != nullptr) +
+                      (net->sW3 != nullptr) + (net->sb3 != nullptr);
+    if (n_sig != 0 && n_sig != 6)
+        return fail(ATACOM_E_INVALID, w + ": the sigma network needs all six weight pointers (or none)");
+    if (net->activation != 0 && net->activation != 1)
+        return fail(ATACOM_E_INVALID, w + ": activation must be 0 (ReLU) or 1 (tanh)");
+    return ATACOM_OK;
+}
 
 extern "C" {
 
@@ -89,6 +129,7 @@ int atacom_get_dims(int32_t env_id, atacom_dims* out) {
     if (!ops || !out) return fail(ATACOM_E_INVALID, "atacom_get_dims: bad env_id or null output");
     out->dim_q = ops->nq; out->n_f = ops->nf; out->n_g = ops->ng; out->n_null = ops->nk;
     out->obs_dim = ops->obs_dim; out->state_dim = ops->state_dim; out->init_state_dim = ops->init_dim;
+    out->record_dim = 2 * ops->obs_dim + ops->nk + 3;
     return ATACOM_OK;
 }
 
@@ -158,23 +199,15 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(ATACOM_E_INVALID, "atacom_create: no such device");
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard guard(device);
+    HIP_TRY(guard.err);
     atacom_handle* h = new atacom_handle();
     h->cfg = *cfg;
     h->device = device;
     h->ops = ops;
     h->f = nullptr; h->ip = nullptr; h->partial_dev = nullptr; h->partial_host = nullptr;
     const size_t B = (size_t)cfg->batch;
-    hipError_t e = hipMalloc(&h->f, ops->elem * ops->n_planes * B);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->ip, sizeof(int) * ops->n_iplanes * B);
-    if (e == hipSuccess) e = hipMalloc((void**)&h->partial_dev, sizeof(double) * 4 * kStatBlocks);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&h->partial_host, sizeof(double) * 4 * kStatBlocks);
-    if (e != hipSuccess) {
-        atacom_destroy(h);
-        return fail(ATACOM_E_HIP, std::string("atacom_create: allocation failed: ") + hipGetErrorString(e));
-    }
-    HIP_TRY(hipMemset(h->f, 0, ops->elem * ops->n_planes * B));
-    HIP_TRY(hipMemset(h->ip, 0, sizeof(int) * ops->n_iplanes * B));
+    void* drow = nullptr;
     // default initial state for every env, then a full reset
     std::vector<double> row;
     default_init_row(cfg->env_id, row);
@@ -183,22 +216,37 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
         if (ops->elem == 4) reinterpret_cast<float*>(bytes.data())[i] = (float)row[i];
         else reinterpret_cast<double*>(bytes.data())[i] = row[i];
     }
-    void* drow = nullptr;
-    HIP_TRY(hipMalloc(&drow, bytes.size()));
-    HIP_TRY(hipMemcpy(drow, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
-    ops->fill_init(h->cfg, h->f, h->ip, drow, nullptr);
-    ops->clear_stats(h->cfg, h->f, h->ip, nullptr);
-    ops->reset(h->cfg, h->f, h->ip, nullptr, nullptr, nullptr, nullptr);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipFree(drow));
+    const char* what = "allocation";
+    hipError_t e = hipMalloc(&h->f, ops->elem * ops->n_planes * B);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->ip, sizeof(int) * ops->n_iplanes * B);
+    if (e == hipSuccess) e = hipMalloc((void**)&h->partial_dev, sizeof(double) * 4 * kStatBlocks);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&h->partial_host, sizeof(double) * 4 * kStatBlocks);
+    if (e == hipSuccess) e = hipMalloc(&drow, bytes.size());
+    if (e == hipSuccess) {
+        what = "initialisation";
+        e = hipMemset(h->f, 0, ops->elem * ops->n_planes * B);
+    }
+    if (e == hipSuccess) e = hipMemset(h->ip, 0, sizeof(int) * ops->n_iplanes * B);
+    if (e == hipSuccess) e = hipMemcpy(drow, bytes.data(), bytes.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        ops->fill_init(h->cfg, h->f, h->ip, drow, nullptr);
+        ops->clear_stats(h->cfg, h->f, h->ip, nullptr);
+        ops->reset(h->cfg, h->f, h->ip, nullptr, nullptr, nullptr, nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (drow) (void)hipFree(drow);
+    if (e != hipSuccess) {                      // one exit for every failure: nothing allocated above survives it
+        atacom_destroy(h);
+        return fail(ATACOM_E_HIP, std::string("atacom_create: ") + what + " failed: " + hipGetErrorString(e));
+    }
     *out = h;
     return ATACOM_OK;
 }
 
 int atacom_destroy(atacom_handle* h) {
     if (!h) return ATACOM_OK;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard(h->device);
     if (h->f) (void)hipFree(h->f);
     if (h->ip) (void)hipFree(h->ip);
     if (h->partial_dev) (void)hipFree(h->partial_dev);
@@ -209,7 +257,7 @@ int atacom_destroy(atacom_handle* h) {
 
 int atacom_reset(atacom_handle* h, const uint8_t* d_mask, const void* d_init_state, void* d_obs, void* stream) {
     if (!h) return fail(ATACOM_E_INVALID, "atacom_reset: null handle");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     h->ops->reset(h->cfg, h->f, h->ip, d_mask, d_init_state, d_obs, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
@@ -220,7 +268,7 @@ int atacom_step(atacom_handle* h, const void* d_action, void* d_obs, void* d_rew
     if (!h) return fail(ATACOM_E_INVALID, "atacom_step: null handle");
     if (!d_action || !d_obs || !d_reward || !d_absorbing)
         return fail(ATACOM_E_INVALID, "atacom_step: d_action, d_obs, d_reward and d_absorbing are required");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     h->ops->step(h->cfg, pick_lanes(h->cfg), h->f, h->ip, d_action, d_obs, d_reward, d_absorbing, d_last, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
@@ -232,9 +280,9 @@ int atacom_rollout(atacom_handle* h, int32_t n_steps, const void* d_actions, voi
     if (n_steps <= 0) return fail(ATACOM_E_INVALID, "atacom_rollout: n_steps must be positive");
     if (!d_actions || !d_obs || !d_reward || !d_absorbing || !d_last)
         return fail(ATACOM_E_INVALID, "atacom_rollout: all buffers except d_next_obs are required");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     h->ops->rollout(h->cfg, pick_lanes(h->cfg), n_steps, h->f, h->ip, d_actions, d_obs, d_next_obs, d_reward, d_absorbing, d_last,
-                    (hipStream_t)stream);
+                    nullptr, 0, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
 }
@@ -243,33 +291,50 @@ int atacom_rollout_mlp(atacom_handle* h, int32_t n_steps, const atacom_mlp* net,
                        void* d_next_obs, void* d_actions, void* d_reward, uint8_t* d_absorbing, uint8_t* d_last,
                        void* stream) {
     if (!h || !net) return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: null handle / network");
-    if (net->struct_size != (int32_t)sizeof(atacom_mlp))
-        return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: atacom_mlp.struct_size mismatch (ABI)");
     if (n_steps <= 0) return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: n_steps must be positive");
-    if (net->n_in != h->ops->obs_dim || net->n_out != h->ops->nk)
-        return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: network n_in / n_out must equal obs_dim / n_null");
-    if (!net->W1 || !net->b1 || !net->W2 || !net->b2 || !net->W3 || !net->b3)
-        return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: null weight pointer");
-    const int n_sig = (net->sW1 != nullptr) + (net->sb1 != nullptr) + (net->sW2 != nullptr) + (net->sb2 != nullptr) +
-                      (net->sW3 != nullptr) + (net->sb3 != nullptr);
-    if (n_sig != 0 && n_sig != 6)
-        return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: the sigma network needs all six weight pointers (or none)");
-    if (net->activation != 0 && net->activation != 1)
-        return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: activation must be 0 (ReLU) or 1 (tanh)");
+    const int vrc = check_mlp(h, net, "atacom_rollout_mlp");
+    if (vrc != ATACOM_OK) return vrc;
     if (!d_obs || !d_actions || !d_reward || !d_absorbing || !d_last)
         return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: all output buffers except d_next_obs are required");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     const int rc = h->ops->rollout_mlp(h->cfg, pick_lanes(h->cfg), n_steps, *net, h->f, h->ip, d_noise, d_obs,
-                                       d_next_obs, d_actions, d_reward, d_absorbing, d_last, (hipStream_t)stream);
+                                       d_next_obs, d_actions, d_reward, d_absorbing, d_last, nullptr, 0,
+                                       (hipStream_t)stream);
     if (rc != ATACOM_OK)
         return fail(ATACOM_E_UNSUPPORTED, "atacom_rollout_mlp: only planar / iiwa with hidden = 64 are compiled in");
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
 }
 
+int atacom_rollout_packed(atacom_handle* h, int32_t n_steps, const void* d_actions, const atacom_mlp* net,
+                          const void* d_noise, void* d_records, int32_t record_batch_stride, void* stream) {
+    if (!h) return fail(ATACOM_E_INVALID, "atacom_rollout_packed: null handle");
+    if (n_steps <= 0) return fail(ATACOM_E_INVALID, "atacom_rollout_packed: n_steps must be positive");
+    if (!d_records) return fail(ATACOM_E_INVALID, "atacom_rollout_packed: d_records is required");
+    if ((d_actions != nullptr) == (net != nullptr))
+        return fail(ATACOM_E_INVALID, "atacom_rollout_packed: give either d_actions or a policy network");
+    if (record_batch_stride < h->cfg.batch)
+        return fail(ATACOM_E_INVALID, "atacom_rollout_packed: record_batch_stride must be >= batch");
+    ON_DEVICE(h);
+    if (d_actions) {
+        h->ops->rollout(h->cfg, pick_lanes(h->cfg), n_steps, h->f, h->ip, d_actions, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, d_records, record_batch_stride, (hipStream_t)stream);
+    } else {
+        const int vrc = check_mlp(h, net, "atacom_rollout_packed");
+        if (vrc != ATACOM_OK) return vrc;
+        const int rc = h->ops->rollout_mlp(h->cfg, pick_lanes(h->cfg), n_steps, *net, h->f, h->ip, d_noise, nullptr, nullptr,
+                                           nullptr, nullptr, nullptr, nullptr, d_records, record_batch_stride,
+                                           (hipStream_t)stream);
+        if (rc != ATACOM_OK)
+            return fail(ATACOM_E_UNSUPPORTED, "atacom_rollout_packed: only planar / iiwa with hidden = 64 are compiled in");
+    }
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+
 int atacom_get_stats(atacom_handle* h, double out[3], int32_t clear, void* stream) {
     if (!h || !out) return fail(ATACOM_E_INVALID, "atacom_get_stats: null argument");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     const int nb = std::min(kStatBlocks, (h->cfg.batch + 255) / 256);
     h->ops->stats(h->cfg, h->f, h->ip, h->partial_dev, nb, s);
@@ -292,7 +357,7 @@ int atacom_get_stats(atacom_handle* h, double out[3], int32_t clear, void* strea
 
 int atacom_get_state(atacom_handle* h, void* d_state, void* stream) {
     if (!h || !d_state) return fail(ATACOM_E_INVALID, "atacom_get_state: null argument");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     h->ops->get_state(h->cfg, h->f, h->ip, d_state, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
@@ -300,7 +365,7 @@ int atacom_get_state(atacom_handle* h, void* d_state, void* stream) {
 
 int atacom_set_state(atacom_handle* h, const void* d_state, void* stream) {
     if (!h || !d_state) return fail(ATACOM_E_INVALID, "atacom_set_state: null argument");
-    HIP_TRY(hipSetDevice(h->device));
+    ON_DEVICE(h);
     h->ops->set_state(h->cfg, h->f, h->ip, d_state, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;

@@ -32,6 +32,14 @@ struct Planes {
     static constexpr int INIT_DIM = 2 * E::NQ + (E::PUCK ? 6 : 0);
 };
 
+// Packed rollout record of one (step, env): the (s, a, r, s', absorbing, last) tuple mushroom_rl.Core collects, as ONE
+// run of F floats -- the layout the sharded collector all-gathers without a repacking pass (rollout.py).
+template <typename E>
+struct Record {
+    static constexpr int OBS = 0, ACT = E::OBS, REW = ACT + E::NK, NOBS = REW + 1, ABS = NOBS + E::OBS, LAST = ABS + 1,
+                         F = LAST + 1;
+};
+
 template <typename T, typename E>
 struct EnvState {
     T q[E::NQ], dq[E::NQ], s[E::NG], puck[6];
@@ -488,8 +496,9 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
                                                   int* __restrict__ ip, const T* __restrict__ actions,
                                                   T* __restrict__ obs, T* __restrict__ next_obs,
                                                   T* __restrict__ reward, uint8_t* __restrict__ absorbing,
-                                                  uint8_t* __restrict__ last) {
+                                                  uint8_t* __restrict__ last, T* __restrict__ rec, int rec_ld) {
     using L = Planes<E>;
+    using R = Record<E>;
     const int B = P.batch;
     const int gt = blockIdx.x * BLOCK<LANES> + threadIdx.x;
     const int b = gt / LANES;
@@ -501,17 +510,33 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
 #pragma unroll 1
     for (int t = 0; t < n_steps; ++t) {
         const size_t row = (size_t)t * B + b;
-        if (lq == 0) write_obs<T, E>(P, st, obs + row * E::OBS);
+        T* const rrow = rec ? rec + ((size_t)t * rec_ld + b) * R::F : nullptr;     // packed record of (t, b)
         T act[E::NK];
 #pragma unroll
         for (int k = 0; k < E::NK; ++k) act[k] = actions[row * E::NK + k];
+        if (lq == 0) {
+            if (rec) {
+                write_obs<T, E>(P, st, rrow + R::OBS);
+#pragma unroll
+                for (int k = 0; k < E::NK; ++k) rrow[R::ACT + k] = act[k];
+            } else {
+                write_obs<T, E>(P, st, obs + row * E::OBS);
+            }
+        }
         StepOut<T> out;
         env_step<T, E, LANES, HOLD>(P, st, act, out, lq);
         if (lq == 0) {
-            if (next_obs) write_obs<T, E>(P, st, next_obs + row * E::OBS);
-            reward[row] = out.reward;
-            absorbing[row] = out.absorbing ? 1 : 0;
-            last[row] = out.last ? 1 : 0;
+            if (rec) {
+                write_obs<T, E>(P, st, rrow + R::NOBS);
+                rrow[R::REW] = out.reward;
+                rrow[R::ABS] = out.absorbing ? T(1) : T(0);
+                rrow[R::LAST] = out.last ? T(1) : T(0);
+            } else {
+                if (next_obs) write_obs<T, E>(P, st, next_obs + row * E::OBS);
+                reward[row] = out.reward;
+                absorbing[row] = out.absorbing ? 1 : 0;
+                last[row] = out.last ? 1 : 0;
+            }
         }
         ssum += out.log_avg;
         scmax = num<T>::max(scmax, out.log_max);
@@ -549,8 +574,9 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
                                                       const T* __restrict__ noise, T* __restrict__ obs,
                                                       T* __restrict__ next_obs, T* __restrict__ actions_out,
                                                       T* __restrict__ reward, uint8_t* __restrict__ absorbing,
-                                                      uint8_t* __restrict__ last) {
+                                                      uint8_t* __restrict__ last, T* __restrict__ rec, int rec_ld) {
     using L = Planes<E>;
+    using R = Record<E>;
     constexpr bool MFMA = MlpPath<T, E, LANES, H>::MFMA;
     constexpr int THREADS = MlpPath<T, E, LANES, H>::THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -607,19 +633,29 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
             act[k] = num<T>::fma(sig[k], eps, act[k]);
             if (net.squash) act[k] = num<T>::tanh(act[k]);
         }
+        T* const rrow = rec ? rec + ((size_t)t * rec_ld + b) * R::F : nullptr;
         if (lq == 0 && valid) {
+            T* const od = rec ? rrow + R::OBS : obs + row * E::OBS;
+            T* const ad = rec ? rrow + R::ACT : actions_out + row * E::NK;
 #pragma unroll
-            for (int i = 0; i < E::OBS; ++i) obs[row * E::OBS + i] = o[i];
+            for (int i = 0; i < E::OBS; ++i) od[i] = o[i];
 #pragma unroll
-            for (int k = 0; k < E::NK; ++k) actions_out[row * E::NK + k] = act[k];
+            for (int k = 0; k < E::NK; ++k) ad[k] = act[k];
         }
         StepOut<T> out;
         env_step<T, E, LANES, HOLD>(P, st, act, out, lq);
         if (lq == 0 && valid) {
-            if (next_obs) write_obs<T, E>(P, st, next_obs + row * E::OBS);
-            reward[row] = out.reward;
-            absorbing[row] = out.absorbing ? 1 : 0;
-            last[row] = out.last ? 1 : 0;
+            if (rec) {
+                write_obs<T, E>(P, st, rrow + R::NOBS);
+                rrow[R::REW] = out.reward;
+                rrow[R::ABS] = out.absorbing ? T(1) : T(0);
+                rrow[R::LAST] = out.last ? T(1) : T(0);
+            } else {
+                if (next_obs) write_obs<T, E>(P, st, next_obs + row * E::OBS);
+                reward[row] = out.reward;
+                absorbing[row] = out.absorbing ? 1 : 0;
+                last[row] = out.last ? 1 : 0;
+            }
         }
         ssum += out.log_avg;
         scmax = num<T>::max(scmax, out.log_max);

@@ -14,11 +14,11 @@ struct EnvOps {
     void (*step)(const atacom_config&, int lanes, void* f, int* ip, const void* act, void* obs, void* rew,
                  uint8_t* ab, uint8_t* last, hipStream_t s);
     void (*rollout)(const atacom_config&, int lanes, int n_steps, void* f, int* ip, const void* acts, void* obs,
-                    void* nobs, void* rew, uint8_t* ab, uint8_t* last, hipStream_t s);
+                    void* nobs, void* rew, uint8_t* ab, uint8_t* last, void* rec, int rec_ld, hipStream_t s);
     // returns 0, or -3 if the (env, hidden size) combination is not compiled in
     int (*rollout_mlp)(const atacom_config&, int lanes, int n_steps, const atacom_mlp& net, void* f, int* ip,
                        const void* noise, void* obs, void* nobs, void* acts, void* rew, uint8_t* ab, uint8_t* last,
-                       hipStream_t s);
+                       void* rec, int rec_ld, hipStream_t s);
     void (*reset)(const atacom_config&, void* f, int* ip, const uint8_t* mask, const void* init, void* obs,
                   hipStream_t s);
     void (*fill_init)(const atacom_config&, void* f, int* ip, const void* row, hipStream_t s);

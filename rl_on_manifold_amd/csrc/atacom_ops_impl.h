@@ -62,28 +62,29 @@ struct Ops {
     }
     template <int LANES, bool HOLD>
     static void launch_rollout(const atacom_config& c, int n_steps, void* f, int* ip, const void* acts, void* obs,
-                               void* nobs, void* rew, uint8_t* ab, uint8_t* last, hipStream_t s) {
+                               void* nobs, void* rew, uint8_t* ab, uint8_t* last, void* rec, int rec_ld, hipStream_t s) {
         hipLaunchKernelGGL((k_rollout<T, E, LANES, HOLD>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)), dim3(BLOCK<LANES>),
                            0, s,
-                           make_params<T>(c), n_steps, (T*)f, ip, (const T*)acts, (T*)obs, (T*)nobs, (T*)rew, ab, last);
+                           make_params<T>(c), n_steps, (T*)f, ip, (const T*)acts, (T*)obs, (T*)nobs, (T*)rew, ab, last,
+                           (T*)rec, rec_ld);
     }
     static void rollout(const atacom_config& c, int lanes, int n_steps, void* f, int* ip, const void* acts, void* obs,
-                        void* nobs, void* rew, uint8_t* ab, uint8_t* last, hipStream_t s) {
+                        void* nobs, void* rew, uint8_t* ab, uint8_t* last, void* rec, int rec_ld, hipStream_t s) {
         if (lanes == 4) {
-            if (c.hold_q) launch_rollout<4, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
-            else launch_rollout<4, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
+            if (c.hold_q) launch_rollout<4, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
+            else launch_rollout<4, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
         } else if (lanes == 2) {
-            if (c.hold_q) launch_rollout<2, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
-            else launch_rollout<2, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
+            if (c.hold_q) launch_rollout<2, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
+            else launch_rollout<2, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
         } else {
-            if (c.hold_q) launch_rollout<1, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
-            else launch_rollout<1, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, s);
+            if (c.hold_q) launch_rollout<1, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
+            else launch_rollout<1, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
         }
     }
     template <int LANES, bool HOLD>
     static void launch_mlp(const atacom_config& c, int n_steps, const MlpArgs<T>& a, void* f, int* ip,
                            const void* noise, void* obs, void* nobs, void* acts, void* rew, uint8_t* ab,
-                           uint8_t* last, hipStream_t s) {
+                           uint8_t* last, void* rec, int rec_ld, hipStream_t s) {
         constexpr int H = 64;
         size_t lds_floats = 2 * MlpLds<E::OBS, H, E::NK>::TOTAL;
         if constexpr (MlpPath<T, E, LANES, H>::MFMA) {
@@ -94,11 +95,11 @@ struct Ops {
         constexpr int THREADS = MlpPath<T, E, LANES, H>::THREADS;
         hipLaunchKernelGGL((k_rollout_mlp<T, E, LANES, HOLD, H>), dim3(nblk(c.batch * LANES, THREADS)), dim3(THREADS),
                            lds_bytes, s, make_params<T>(c), a, n_steps, (T*)f, ip, (const T*)noise, (T*)obs, (T*)nobs,
-                           (T*)acts, (T*)rew, ab, last);
+                           (T*)acts, (T*)rew, ab, last, (T*)rec, rec_ld);
     }
     static int rollout_mlp(const atacom_config& c, int lanes, int n_steps, const atacom_mlp& net, void* f, int* ip,
                            const void* noise, void* obs, void* nobs, void* acts, void* rew, uint8_t* ab, uint8_t* last,
-                           hipStream_t s) {
+                           void* rec, int rec_ld, hipStream_t s) {
         if (E::ID == 0 || net.hidden != 64) return ATACOM_E_UNSUPPORTED;
         MlpArgs<T> a;
         a.W1 = (const T*)net.W1; a.b1 = (const T*)net.b1; a.W2 = (const T*)net.W2; a.b2 = (const T*)net.b2;
@@ -110,14 +111,14 @@ struct Ops {
         a.n_in = net.n_in; a.n_out = net.n_out; a.activation = net.activation;
         if constexpr (E::ID != 0) {
             if (lanes == 4) {
-                if (c.hold_q) launch_mlp<4, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
-                else launch_mlp<4, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
+                if (c.hold_q) launch_mlp<4, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
+                else launch_mlp<4, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
             } else if (lanes == 2) {
-                if (c.hold_q) launch_mlp<2, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
-                else launch_mlp<2, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
+                if (c.hold_q) launch_mlp<2, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
+                else launch_mlp<2, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
             } else {
-                if (c.hold_q) launch_mlp<1, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
-                else launch_mlp<1, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, s);
+                if (c.hold_q) launch_mlp<1, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
+                else launch_mlp<1, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
             }
         }
         return ATACOM_OK;

@@ -70,6 +70,7 @@ class BatchedAtacomEnv:
         d = _lib.get_dims(self.env_id)
         self.dims = {'q': d.dim_q, 'f': d.n_f, 'g': d.n_g, 'null': d.n_null, 'c': d.n_f + d.n_g}   # atacom.py:25-40
         self.obs_dim, self.state_dim, self.init_state_dim = d.obs_dim, d.state_dim, d.init_state_dim
+        self.record_dim = d.record_dim
         # get_dims reports the ACTION dimension in n_null: dim_q - n_f for ATACOM (atacom.py:39,51), dim_q for the
         # 'E' / 'T' baselines (error_correction_wrapper.py:48, circle_base.py:24)
         if Kc is not None:
@@ -172,6 +173,39 @@ class BatchedAtacomEnv:
                                                  _ptr(out['next_obs']), _ptr(out['action']), _ptr(out['reward']),
                                                  _ptr(out['absorbing']), _ptr(out['last']), self._stream()))
         return out
+
+    def rollout_packed(self, actions=None, policy=None, n_steps=None, noise=None, out=None, batch_stride=None):
+        """T env steps in one launch, written as ONE packed float record per (step, env):
+        records [T, batch_stride, record_dim] = [obs | action | reward | next_obs | absorbing | last] -- the layout the
+        sharded collector all-gathers as it is (rollout.py).  Either `actions` [T, B, k] or `policy` (an MlpPolicy,
+        evaluated inside the kernel; `noise` [T, B, k] or None) with `n_steps`.  batch_stride > batch pads the env axis
+        (ragged shards); the padding rows are zero-filled once at allocation and never written."""
+        B, k, F = self.batch, self.dims['null'], self.record_dim
+        if (actions is None) == (policy is None):
+            raise ValueError("give either actions or policy")
+        T = int(actions.shape[0]) if actions is not None else int(n_steps)
+        ld = B if batch_stride is None else int(batch_stride)
+        if out is None:
+            alloc = torch.empty if ld == B else torch.zeros
+            out = alloc((T, ld, F), device=self.device, dtype=self.dtype)
+        elif tuple(out.shape) != (T, ld, F) or not out.is_contiguous() or out.dtype != self.dtype:
+            raise ValueError("out must be a contiguous [%d, %d, %d] tensor of the engine's dtype" % (T, ld, F))
+        if actions is not None:
+            a = self._as_dev(actions, (T, B, k))
+            _lib.check(self._lib.atacom_rollout_packed(self._h, T, _ptr(a), None, None, _ptr(out), ld, self._stream()))
+        else:
+            net = policy.as_struct(self)
+            nz = None if noise is None else self._as_dev(noise, (T, B, k))
+            _lib.check(self._lib.atacom_rollout_packed(self._h, T, None, C.byref(net), _ptr(nz), _ptr(out), ld,
+                                                        self._stream()))
+        return out
+
+    def unpack_records(self, rec):
+        """Views into packed records [..., record_dim] (no copy)."""
+        D, k = self.obs_dim, self.dims['null']
+        return {'obs': rec[..., :D], 'action': rec[..., D:D + k], 'reward': rec[..., D + k],
+                'next_obs': rec[..., D + k + 1:2 * D + k + 1], 'absorbing': rec[..., 2 * D + k + 1] > 0.5,
+                'last': rec[..., 2 * D + k + 2] > 0.5}
 
     def get_constraints_logs(self, clear=True):
         res = (C.c_double * 3)()

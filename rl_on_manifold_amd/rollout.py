@@ -6,13 +6,17 @@ runs on "gloo" for the CPU tests).
 The reference has no distributed code at all; this is the data-parallel axis the
 workload offers: BASELINE.json config 5 = 65536 IiwaAirHockey envs = 8 GPUs x 8192.
 
-What is gathered: the (state, action, reward, next_state, absorbing, last) tuples mushroom_rl.Core.learn hands to
-an on-policy agent (PPO / TRPO fit on the whole dataset), packed into ONE float buffer [T, B_local, F] per
-rank so a single large collective moves it (for config 5: 120 x 8192 x 44 floats = 173 MB per rank).  xGMI is
-point-to-point, so one big all-gather amortises the per-link setup far better than six small ones.
+Data path of one collection (every pass over the data is listed; there are two):
+  1. the rollout kernel writes the (state, action, reward, next_state, absorbing, last) tuples mushroom_rl.Core.learn
+     hands to an on-policy agent as packed float records [T, B_shard, F] (atacom_rollout_packed, one launch);
+  2. one `all_gather_into_tensor` of that buffer into [W, T, B_shard, F] -- which IS the final layout
+     ("shard-major"): `unpack` returns views into it, `reshape(-1, F)` is the flat sample set a PPO / TRPO fit
+     consumes, and the time axis of every environment stays strided-contiguous for GAE.
+No size exchange (every rank's shard size is a pure function of (global_batch, world)), no packing copy, no
+concatenation.  For config 5: 120 x 8192 x 44 floats = 173 MB sent per rank, 1.38 GB received; xGMI is
+point-to-point, so one large collective amortises the per-link setup far better than six small ones.
 Constraint statistics are reduced with one MAX and one SUM all-reduce of two numbers each.
 """
-import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -27,31 +31,50 @@ def shard_bounds(global_batch, world_size, rank):
 class RolloutCollector:
     """Drive one local engine (a BatchedAtacomEnv, or anything with its surface) and assemble global rollouts.
 
-    env        : local engine holding this rank's shard (env.batch envs)
-    group      : torch.distributed process group (None = default group; no-op if dist is not initialised)
+    env          : local engine holding this rank's shard (env.batch envs)
+    group        : torch.distributed process group (None = default group; no-op if dist is not initialised)
+    global_batch : total number of envs over all ranks (default env.batch * world, i.e. equal shards); ragged
+                   shards follow shard_bounds(global_batch, world, rank) and are padded to the largest shard
     """
 
-    def __init__(self, env, group=None):
+    def __init__(self, env, group=None, global_batch=None):
         self.env = env
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.rank = dist.get_rank(group) if self.distributed else 0
+        self.global_batch = int(global_batch) if global_batch is not None else env.batch * self.world
+        self.sizes = []
+        for r in range(self.world):
+            lo, hi = shard_bounds(self.global_batch, self.world, r)
+            self.sizes.append(hi - lo)
+        if self.sizes[self.rank] != env.batch:
+            raise ValueError("rank %d holds %d envs, shard_bounds(%d, %d) assigns it %d"
+                             % (self.rank, env.batch, self.global_batch, self.world, self.sizes[self.rank]))
+        self.Bm = max(self.sizes)                 # env-axis length of every rank's send buffer
         self.k = env.dims['null']
         self.D = env.obs_dim
         self.F = 2 * self.D + self.k + 3          # obs, action, reward, next_obs, absorbing, last
+        self._recv = None
 
     # ------------------------------------------------------------------ local collection
-    def collect_local(self, n_steps, actions=None, policy=None):
-        """T = n_steps env steps of the local shard.  Either `actions` [T, B_local, k] (pre-generated, ONE kernel
-        launch via env.rollout) or `policy(obs) -> actions` (one launch per step).  Returns the packed buffer
-        [T, B_local, F]."""
+    def collect_local(self, n_steps, actions=None, policy=None, noise=None, out=None):
+        """T = n_steps env steps of the local shard -> packed records [T, Bm, F].
+        actions [T, B_local, k]  : pre-generated actions, ONE kernel launch;
+        policy = MlpPolicy       : the actor network evaluated inside the rollout kernel, ONE launch (`noise` optional);
+        policy = callable        : policy(obs) -> actions, one launch per step (host-driven loop)."""
         env = self.env
+        fused = hasattr(env, 'rollout_packed')
+        if fused and actions is not None:
+            return env.rollout_packed(actions=actions, out=out, batch_stride=self.Bm)
+        if fused and policy is not None and hasattr(policy, 'as_struct'):
+            return env.rollout_packed(policy=policy, n_steps=n_steps, noise=noise, out=out, batch_stride=self.Bm)
+        # engines without the packed kernel (the CPU test double) and host-side policies: pack here
         B = env.batch
         if actions is not None:
-            out = env.rollout(actions)
-            obs, nobs, rew = out['obs'], out['next_obs'], out['reward']
-            ab, last, act = out['absorbing'], out['last'], out['action']
+            o = env.rollout(actions)
+            obs, nobs, rew = o['obs'], o['next_obs'], o['reward']
+            ab, last, act = o['absorbing'], o['last'], o['action']
         else:
             assert policy is not None
             obs_l, act_l, rew_l, nobs_l, ab_l, last_l = [], [], [], [], [], []
@@ -72,49 +95,58 @@ class RolloutCollector:
             obs, act, rew = torch.stack(obs_l), torch.stack(act_l), torch.stack(rew_l)
             nobs, ab, last = torch.stack(nobs_l), torch.stack(ab_l), torch.stack(last_l)
         T = obs.shape[0]
-        buf = torch.empty((T, B, self.F), device=obs.device, dtype=obs.dtype)
+        buf = torch.zeros((T, self.Bm, self.F), device=obs.device, dtype=obs.dtype) if out is None else out
         D, k = self.D, self.k
-        buf[..., :D] = obs
-        buf[..., D:D + k] = act
-        buf[..., D + k] = rew
-        buf[..., D + k + 1:2 * D + k + 1] = nobs
-        buf[..., 2 * D + k + 1] = ab.to(obs.dtype)
-        buf[..., 2 * D + k + 2] = last.to(obs.dtype)
+        buf[:, :B, :D] = obs
+        buf[:, :B, D:D + k] = act
+        buf[:, :B, D + k] = rew
+        buf[:, :B, D + k + 1:2 * D + k + 1] = nobs
+        buf[:, :B, 2 * D + k + 1] = ab.to(obs.dtype)
+        buf[:, :B, 2 * D + k + 2] = last.to(obs.dtype)
         return buf
 
     # ------------------------------------------------------------------ the one collective
-    def gather(self, buf):
-        """All-gather the packed rollout: [T, B_local, F] on every rank -> [T, B_global, F] on every rank
-        (rank r's envs occupy the contiguous block shard_bounds(...) gives it)."""
+    def gather(self, buf, out=None):
+        """All-gather the packed rollout: [T, Bm, F] on every rank -> [W, T, Bm, F] on every rank, rank r's shard in
+        block r (its first sizes[r] env rows are valid).  One collective, written straight into the final buffer."""
         if self.world == 1:
-            return buf
-        T, B, F = buf.shape
-        # equal shards are the common case (one all_gather_into_tensor); ragged shards fall back to padding
-        bmax = torch.tensor([B], device=buf.device, dtype=torch.int64)
-        blist = [torch.zeros_like(bmax) for _ in range(self.world)]
-        dist.all_gather(blist, bmax, group=self.group)
-        bs = [int(x.item()) for x in blist]
-        Bm = max(bs)
-        send = buf if B == Bm else torch.cat([buf, buf.new_zeros((T, Bm - B, F))], 1)
-        send = send.contiguous()
-        recv = torch.empty((self.world, T, Bm, F), device=buf.device, dtype=buf.dtype)
-        try:
-            dist.all_gather_into_tensor(recv, send, group=self.group)
-        except (RuntimeError, NotImplementedError):
-            parts = [torch.empty_like(send) for _ in range(self.world)]
-            dist.all_gather(parts, send, group=self.group)
-            recv = torch.stack(parts)
-        return torch.cat([recv[r, :, :bs[r]] for r in range(self.world)], 1)
+            return buf.unsqueeze(0)
+        T, Bm, F = buf.shape
+        shape = (self.world, T, Bm, F)
+        if buf.is_cuda and dist.get_backend(self.group) == 'gloo':
+            # gloo moves host memory: the control-flow check mode (several ranks sharing one GPU in the tests;
+            # BENCH_DIST_BACKEND=gloo).  The production transport is RCCL, device to device, below.
+            host = torch.empty(shape, dtype=buf.dtype)
+            dist.all_gather_into_tensor(host.view(self.world * T, Bm, F), buf.cpu(), group=self.group)
+            return host.to(buf.device)
+        if out is None:
+            if self._recv is None or tuple(self._recv.shape) != shape or self._recv.dtype != buf.dtype \
+                    or self._recv.device != buf.device:
+                self._recv = torch.empty(shape, device=buf.device, dtype=buf.dtype)
+            out = self._recv
+        # output handed over as the concatenation along dim 0 (the form every backend accepts)
+        dist.all_gather_into_tensor(out.view(self.world * T, Bm, F), buf, group=self.group)
+        return out
 
-    def unpack(self, buf):
+    def unpack(self, g):
+        """Views (no copy) into gathered records [W, T, Bm, F]: every entry is [W, T, Bm, ...]."""
         D, k = self.D, self.k
-        return {'obs': buf[..., :D], 'action': buf[..., D:D + k], 'reward': buf[..., D + k],
-                'next_obs': buf[..., D + k + 1:2 * D + k + 1], 'absorbing': buf[..., 2 * D + k + 1] > 0.5,
-                'last': buf[..., 2 * D + k + 2] > 0.5}
+        return {'obs': g[..., :D], 'action': g[..., D:D + k], 'reward': g[..., D + k],
+                'next_obs': g[..., D + k + 1:2 * D + k + 1], 'absorbing': g[..., 2 * D + k + 1] > 0.5,
+                'last': g[..., 2 * D + k + 2] > 0.5}
 
-    def collect(self, n_steps, actions=None, policy=None):
-        """Local rollout + global all-gather.  Returns the unpacked global dataset (time-major)."""
-        return self.unpack(self.gather(self.collect_local(n_steps, actions=actions, policy=policy)))
+    def time_major(self, data):
+        """[W, T, Bm, ...] -> [T, B_global, ...] with rank r's envs in block shard_bounds(global_batch, W, r).
+        This one COPIES (a permute + concatenation); it is for consumers that insist on a single env axis and for
+        comparing against a single-process run -- the collection path itself never needs it."""
+        out = {}
+        for key, v in data.items():
+            out[key] = torch.cat([v[r, :, :self.sizes[r]] for r in range(self.world)], 1)
+        return out
+
+    def collect(self, n_steps, actions=None, policy=None, noise=None):
+        """Local rollout + global all-gather.  Returns the unpacked global dataset, shard-major [W, T, Bm, ...]."""
+        return self.unpack(self.gather(self.collect_local(n_steps, actions=actions, policy=policy, noise=noise)))
 
     # ------------------------------------------------------------------ constraint statistics
     def get_constraints_logs(self, n_logged):
@@ -124,6 +156,8 @@ class RolloutCollector:
         if self.world == 1:
             return c_avg, c_max, c_dq
         dev = getattr(self.env, 'device', torch.device('cpu'))
+        if self.distributed and dist.get_backend(self.group) == 'gloo':
+            dev = torch.device('cpu')
         mx = torch.tensor([c_max, c_dq], dtype=torch.float64, device=dev)
         sm = torch.tensor([c_avg * n_logged, float(n_logged)], dtype=torch.float64, device=dev)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
@@ -132,8 +166,8 @@ class RolloutCollector:
 
 
 def to_mushroom_dataset(data):
-    """Flatten a time-major rollout into MushroomRL's list-of-tuples dataset (s, a, r, s', absorbing, last),
-    env by env (what Core.learn would have produced running the envs one after another)."""
+    """Flatten a time-major rollout [T, B, ...] into MushroomRL's list-of-tuples dataset (s, a, r, s', absorbing,
+    last), env by env (what Core.learn would have produced running the envs one after another)."""
     obs, act, rew = (data[k].cpu().numpy() for k in ('obs', 'action', 'reward'))
     nobs, ab, last = (data[k].cpu().numpy() for k in ('next_obs', 'absorbing', 'last'))
     T, B = rew.shape

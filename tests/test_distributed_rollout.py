@@ -37,8 +37,10 @@ def _worker(rank, world, port, q):
         from oracle_engine import OracleEngine
         lo, hi = shard_bounds(GLOBAL_B, world, rank)
         eng = OracleEngine(NAME, hi - lo, init_q=_init_q()[lo:hi], horizon=5)
-        col = RolloutCollector(eng)
-        data = col.collect(T, actions=_actions()[:, lo:hi])
+        col = RolloutCollector(eng, global_batch=GLOBAL_B)
+        sm = col.collect(T, actions=_actions()[:, lo:hi])             # shard-major views [W, T, Bm, ...]
+        assert sm['obs'].shape[:3] == (world, T, max(col.sizes))
+        data = col.time_major(sm)
         stats = col.get_constraints_logs(n_logged=T * (hi - lo))
         q.put((rank, {k: v.numpy() for k, v in data.items()}, stats))
         dist.barrier()
@@ -69,7 +71,8 @@ def test_two_rank_gloo_rollout_equals_single_process(world):
         assert p.exitcode == 0
     # single-process reference over the whole batch
     eng = OracleEngine(NAME, GLOBAL_B, init_q=_init_q(), horizon=5)
-    ref = RolloutCollector(eng).collect(T, actions=_actions())
+    rc = RolloutCollector(eng)
+    ref = rc.time_major(rc.collect(T, actions=_actions()))
     ref_stats = eng.get_constraints_logs()
     for rank, data, stats in results:
         for k in ('obs', 'action', 'reward', 'next_obs', 'absorbing', 'last'):
@@ -87,7 +90,7 @@ def test_policy_driven_collection_and_mushroom_dataset():
     eng = OracleEngine('circle', 4, horizon=6)
     col = RolloutCollector(eng)
     rng = np.random.default_rng(0)
-    data = col.collect(9, policy=lambda obs: rng.uniform(-1, 1, (4, 1)))
+    data = col.time_major(col.collect(9, policy=lambda obs: rng.uniform(-1, 1, (4, 1))))
     assert data['obs'].shape == (9, 4, 4) and data['action'].shape == (9, 4, 1)
     assert data['last'][5].all() and data['last'].sum() == 4
     ds = to_mushroom_dataset(data)

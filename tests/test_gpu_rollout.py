@@ -1,0 +1,201 @@
+"""GPU tests of the collection path: the packed-record rollout kernels, the RolloutCollector
+over the real HIP engine (world 1, and two processes sharing one GPU), and bench.py's own rank spawning."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = 'cuda:0'
+KEYS = ('obs', 'action', 'reward', 'next_obs', 'absorbing', 'last')
+
+
+def _env(name, B, **kw):
+    from rl_on_manifold_amd import BatchedAtacomEnv
+    return BatchedAtacomEnv(name, B, device=DEV, dtype=torch.float32, auto_reset=True, **kw)
+
+
+def _policy(D, k, seed=0):
+    from rl_on_manifold_amd import MlpPolicy
+    g = torch.Generator().manual_seed(seed)
+    return MlpPolicy(torch.randn(64, D, generator=g) * 0.2, torch.randn(64, generator=g) * 0.1,
+                     torch.randn(64, 64, generator=g) * 0.1, torch.randn(64, generator=g) * 0.1,
+                     torch.randn(k, 64, generator=g) * 0.1, torch.zeros(k), std=torch.full((k,), 0.3))
+
+
+@pytest.mark.parametrize('lanes', [1, 2, 4])
+@pytest.mark.parametrize('name', ['circle', 'planar', 'iiwa'])
+def test_packed_rollout_is_bitwise_the_array_rollout(name, lanes):
+    """atacom_rollout_packed writes exactly what atacom_rollout writes, as one record per (step, env); a padded env
+    axis (ragged shards) leaves the padding rows untouched."""
+    B, T = 333, 17
+    env = _env(name, B, lanes_per_env=lanes, horizon=7)
+    k = env.dims['null']
+    g = torch.Generator(device=DEV).manual_seed(1)
+    acts = torch.rand((T, B, k), device=DEV, generator=g) * 2.4 - 1.2
+    st = env.get_state()
+    ref = env.rollout(acts)
+    env.set_state(st)
+    rec = env.rollout_packed(actions=acts, batch_stride=B + 5)
+    assert rec.shape == (T, B + 5, env.record_dim)
+    assert (rec[:, B:] == 0).all()
+    got = env.unpack_records(rec[:, :B])
+    for key in KEYS:
+        a, b = got[key], ref[key]
+        assert torch.equal(a.float(), b.float()), key
+    assert got['last'][6].all()                                        # horizon 7, auto-reset
+
+
+@pytest.mark.parametrize('name', ['planar', 'iiwa'])
+def test_packed_policy_rollout_is_bitwise_the_array_policy_rollout(name):
+    B, T = 200, 9
+    env = _env(name, B)
+    pol = _policy(env.obs_dim, env.dims['null'])
+    g = torch.Generator(device=DEV).manual_seed(2)
+    eps = torch.randn((T, B, env.dims['null']), device=DEV, generator=g)
+    st = env.get_state()
+    ref = env.rollout_policy(pol, T, noise=eps)
+    env.set_state(st)
+    got = env.unpack_records(env.rollout_packed(policy=pol, n_steps=T, noise=eps))
+    for key in KEYS:
+        assert torch.equal(got[key].float(), ref[key].float()), key
+
+
+def test_collector_over_the_hip_engine_world_1():
+    """RolloutCollector driving a real BatchedAtacomEnv: fused actions path, fused policy path, host-policy path."""
+    from rl_on_manifold_amd.rollout import RolloutCollector, to_mushroom_dataset
+    B, T = 96, 11
+    env = _env('iiwa', B, horizon=5)
+    col = RolloutCollector(env)
+    k = env.dims['null']
+    g = torch.Generator(device=DEV).manual_seed(3)
+    acts = torch.rand((T, B, k), device=DEV, generator=g) * 2 - 1
+    st = env.get_state()
+    ref = env.rollout(acts)
+    env.set_state(st)
+    data = col.collect(T, actions=acts)
+    assert data['obs'].shape == (1, T, B, env.obs_dim) and data['obs'].is_cuda
+    assert data['absorbing'].dtype == torch.bool and data['last'].dtype == torch.bool
+    tm = col.time_major(data)
+    for key in KEYS:
+        assert torch.equal(tm[key].float(), ref[key].float()), key
+    ds = to_mushroom_dataset(tm)
+    assert len(ds) == T * B and ds[4][5] is True
+    # fused policy
+    pol = _policy(env.obs_dim, k)
+    data = col.collect(T, policy=pol, noise=torch.randn((T, B, k), device=DEV, generator=g))
+    assert data['action'].shape == (1, T, B, k) and torch.isfinite(data['reward']).all()
+    # host-side policy (one launch per step)
+    data = col.collect(T, policy=lambda o: torch.zeros((B, k), device=DEV))
+    assert data['obs'].shape == (1, T, B, env.obs_dim)
+    c_avg, c_max, c_dq = col.get_constraints_logs(n_logged=3 * T * B)
+    assert np.isfinite([c_avg, c_max, c_dq]).all()
+
+
+def _worker(rank, world, port, gb, T, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from rl_on_manifold_amd import BatchedAtacomEnv
+        from rl_on_manifold_amd.rollout import RolloutCollector, shard_bounds
+        lo, hi = shard_bounds(gb, world, rank)
+        env = BatchedAtacomEnv('planar', hi - lo, device=DEV, dtype=torch.float32, auto_reset=True, horizon=6)
+        g = torch.Generator().manual_seed(9)
+        acts = (torch.rand((T, gb, 3), generator=g) * 2 - 1)[:, lo:hi].to(DEV)
+        init = torch.zeros((gb, env.init_state_dim))
+        init[:, :3] = torch.tensor([-0.9273, 0.9273, np.pi / 2]) + 0.03 * torch.randn((gb, 3), generator=g)
+        init[:, 6] = -0.5
+        env.reset(state=init[lo:hi].to(DEV))
+        col = RolloutCollector(env, global_batch=gb)
+        data = col.time_major(col.collect(T, actions=acts))
+        stats = col.get_constraints_logs(n_logged=T * (hi - lo))
+        q.put((rank, {k_: v.cpu().numpy() for k_, v in data.items()}, stats))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_collector_two_processes_sharing_the_gpu_equal_one_process():
+    """Two ranks (ragged shards 6 + 5), each with its own HIP engine on the same GPU, gloo as the transport (RCCL
+    refuses two ranks on one device): the gathered global dataset equals a single-process run."""
+    import torch.multiprocessing as mp
+    gb, T, world = 11, 13, 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29800 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, gb, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from rl_on_manifold_amd.rollout import RolloutCollector
+    env = _env('planar', gb, horizon=6)
+    g = torch.Generator().manual_seed(9)
+    acts = (torch.rand((T, gb, 3), generator=g) * 2 - 1).to(DEV)
+    init = torch.zeros((gb, env.init_state_dim))
+    init[:, :3] = torch.tensor([-0.9273, 0.9273, np.pi / 2]) + 0.03 * torch.randn((gb, 3), generator=g)
+    init[:, 6] = -0.5
+    env.reset(state=init.to(DEV))
+    col = RolloutCollector(env)
+    ref = col.time_major(col.collect(T, actions=acts))
+    ref_stats = env.get_constraints_logs()
+    for rank, data, stats in results:
+        for key in KEYS:
+            assert data[key].shape == tuple(ref[key].shape), key
+            assert np.array_equal(data[key], ref[key].cpu().numpy()), (rank, key)
+        assert np.allclose(stats, ref_stats, rtol=1e-6, atol=1e-7)
+
+
+def test_calls_leave_the_current_device_alone():
+    """no entry point may change the calling thread's current HIP device."""
+    if torch.cuda.device_count() < 2:
+        env = _env('circle', 8)
+        env.step(torch.zeros((8, 1), device=DEV))
+        assert torch.cuda.current_device() == 0
+        return
+    from rl_on_manifold_amd import BatchedAtacomEnv
+    torch.cuda.set_device(0)
+    env = BatchedAtacomEnv('circle', 8, device='cuda:1')
+    assert torch.cuda.current_device() == 0
+    env.step(torch.zeros((8, 1), device='cuda:1'))
+    env.get_constraints_logs()
+    env.get_state()
+    env.close()
+    assert torch.cuda.current_device() == 0
+
+
+def _run_bench(extra, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '20', '--warmup', '5',
+                        '--min-time', '0.1', '--no-cpu-baseline', '--no-secondary'] + extra,
+                       capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    return json.loads(line)
+
+
+def test_bench_line_single_gpu():
+    res = _run_bench(['--gpus', '1'])
+    assert res['n_gpus'] == 1 and res['steps'] == 20 and res['timing']['blocks'] >= 3
+    assert res['config']['batch_per_gpu'] == 8192 and 'IiwaAirHockey' in res['config']['workload']
+    assert 0 < res['max_abs_c'] < 0.05                       # feasible initial states: the engine's residual, not the init's
+    assert res['collection']['records'] == [1, 120, 8192, 44] and res['collection']['allgather_ms'] is None
+    assert abs(res['roofline']['frac'] - res['roofline']['achieved'] / 8000.0) < 1e-12
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` launches two ranks itself (gloo here: two ranks share the one GPU of this box)."""
+    res = _run_bench(['--gpus', '2', '--batch', '2048'], env={'BENCH_DIST_BACKEND': 'gloo'})
+    assert res['n_gpus'] == 2 and res['config']['global_batch'] == 4096
+    assert res['collection']['records'] == [2, 120, 2048, 44] and res['collection']['allgather_ms'] > 0
