@@ -402,6 +402,27 @@ def secondary_records(dev, gen, K, W, sync_all, max_over_ranks):
     return out
 
 
+def usable_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container that
+    sees 256 CPUs but is throttled to 16 cores' worth of time gains nothing from 256 workers)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(env_name, budget_s, dev, init, k):
     """The oracle as the CPU baseline ("port"; the reference itself needs Pinocchio / PyBullet / MushroomRL and never
     travels to this box).  Three legs on the host cores of the GPU box:
@@ -414,7 +435,7 @@ def cpu_baseline(env_name, budget_s, dev, init, k):
     import torch
     from oracle import cpu_legs
     from rl_on_manifold_amd import BatchedAtacomEnv
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = usable_cores()
     one = cpu_legs.scalar_leg((env_name, budget_s, 0))
     ctx = mp.get_context('spawn')
     t0 = time.perf_counter()
@@ -448,7 +469,7 @@ def cpu_baseline(env_name, budget_s, dev, init, k):
                                  'oracle_f64': {'c_avg': ora['c_avg'], 'c_max': ora['c_max'], 'c_dq_max': ora['c_dq_max']},
                                  'device_f32': {'c_avg': d_avg, 'c_max': d_max, 'c_dq_max': d_dq},
                                  'c_max_ratio_device_over_oracle': d_max / ora['c_max'] if ora['c_max'] else None},
-            'host_cpus_visible': os.cpu_count()}
+            'host_cpus_visible': os.cpu_count(), 'host_cpus_usable': cores}
 
 
 if __name__ == '__main__':

@@ -20,6 +20,10 @@ Golden sets:
   G7 logs           get_constraints_logs aggregation
   G9 baselines      CircleEnvErrorCorrection / CircleEnvTerminated trajectories (row N3)
   G8 policy         the reference's actor networks (examples/network.py) forward() on random inputs (row N2)
+  G10 urdf          the reference's OWN iiwa_1.urdf evaluated by a generic URDF tree evaluator (oracle/urdf_model.py,
+                    xml.etree -- no hand-unrolled constant): position, 6 x n LOCAL_WORLD_ALIGNED Jacobian, w x v and
+                    exact dJ/dt dq of the three constraint frames (tip = joint 7 + 0.585 z, link_4, link_7), joint
+                    limits; + rigid-body dynamics of the same file (mass matrix, inverse dynamics) for row N4
 """
 import os
 import sys
@@ -456,8 +460,62 @@ def gen_policy():
     print('policy_net.npz', sorted(out)[:6], '...')
 
 
+IIWA_URDF = '/root/reference/atacom/environments/iiwa_air_hockey/urdf/iiwa_1.urdf'
+
+
+def gen_urdf():
+    """G10 / G11.  Frame bookkeeping of the reference (Pinocchio's URDF parser numbers frames: 0 universe, 1 root_joint,
+    2 world, then one FIXED_JOINT/JOINT + one BODY frame per URDF joint in chain order: base_joint 3, link_0 4, joint_1 5,
+    link_1 6, ..., joint_4 11, link_4 12, ..., joint_7 17, link_7 18): frame_idx_4 = 12 and frame_idx_7 = 18
+    (iiwa_hit_atacom.py:45-46) are the link_4 and link_7 BODY frames; the tip is addBodyFrame('striker_rod_tip',
+    joint 7, translation (0, 0, 0.585)) (env_base.py:147-151)."""
+    from oracle.urdf_model import UrdfModel
+    m = UrdfModel(IIWA_URDF)
+    names = [j['name'] for j in m.movable]
+    assert names[:7] == ['iiwa_1/joint_%d' % i for i in range(1, 8)] and m.nq == 9, names
+    frames = {'ee': ('iiwa_1/link_7', (0.0, 0.0, 0.585)), 'link_4': ('iiwa_1/link_4', (0.0, 0.0, 0.0)),
+              'link_7': ('iiwa_1/link_7', (0.0, 0.0, 0.0))}
+    rng = np.random.default_rng(1010)
+    upper = np.array([j['upper'] for j in m.movable])
+    vel = np.array([j['velocity'] for j in m.movable])
+    n = 256
+    q = rng.uniform(-1.0, 1.0, (n, 6)) * upper[:6]
+    dq = rng.uniform(-1.0, 1.0, (n, 6)) * vel[:6]
+    q[0] = 0.0                                              # singular, symmetric pose
+    q[1] = iiwa_init_q()                                    # the reset pose
+    q[2:34] = iiwa_init_q() + rng.normal(0, 0.05, (32, 6))  # the neighbourhood the benchmark runs in
+    dq[0] = 0.0
+    out = {'q': q, 'dq': dq, 'pos_upper': upper, 'vel_limit': vel,
+           'damping': np.array([j['damping'] for j in m.movable]),
+           'joint_names': np.array(names)}
+    for fr, (ln, off) in frames.items():
+        pos, J, wxv, jdq = [], [], [], []
+        for i in range(n):
+            pos.append(m.frame(q[i], ln, off)[0])
+            J.append(m.frame_jacobian(q[i], ln, off)[:, :6])
+            mo = m.frame_motion(q[i], dq[i], ln, off)
+            wxv.append(mo['w_cross_v'])
+            jdq.append(mo['a_classical'])
+        out[fr + '_pos'], out[fr + '_J'] = np.array(pos), np.array(J)
+        out[fr + '_wxv'], out[fr + '_jdotqdot'] = np.array(wxv), np.array(jdq)
+    # G11: dynamics of all 9 movable joints (7 arm + 2 striker), 64 states
+    nd = 64
+    q9 = rng.uniform(-1.0, 1.0, (nd, 9)) * np.minimum(upper, 1.5)
+    dq9 = rng.uniform(-1.0, 1.0, (nd, 9))
+    ddq9 = rng.uniform(-3.0, 3.0, (nd, 9))
+    q9[0] = 0.0
+    q9[1, :6], q9[1, 6:] = iiwa_init_q(), 0.0
+    out['dyn_q'], out['dyn_dq'], out['dyn_ddq'] = q9, dq9, ddq9
+    out['dyn_M'] = np.array([m.mass_matrix(q9[i]) for i in range(nd)])
+    out['dyn_tau'] = np.array([m.rnea(q9[i], dq9[i], ddq9[i]) for i in range(nd)])
+    out['dyn_gravity'] = np.array([m.rnea(q9[i], np.zeros(9), np.zeros(9)) for i in range(nd)])
+    out['dyn_energy'] = np.array([m.energy(q9[i], dq9[i]) for i in range(nd)])
+    np.savez_compressed(os.path.join(OUT, 'iiwa_urdf.npz'), **out)
+    print('iiwa_urdf.npz', {k: v.shape for k, v in out.items() if k.endswith('_J') or k.startswith('dyn_M')})
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    todo = sys.argv[1:] or ['nullspace', 'constraints', 'circle', 'generic', 'tables', 'policy', 'baselines']
+    todo = sys.argv[1:] or ['nullspace', 'constraints', 'circle', 'generic', 'tables', 'policy', 'baselines', 'urdf']
     for name in todo:
         globals()['gen_' + name]()

@@ -99,6 +99,26 @@ def test_constraint_terms_against_oracle(name, bias, dt):
     assert (J.cpu().numpy()[1:][(Jo == 0)[1:]] == 0).all()       # exact zeros of the oracle are exact on the device
 
 
+@pytest.mark.parametrize('dt', ['f64', 'f32'])
+@pytest.mark.parametrize('bias', ['reference', 'exact'])
+def test_iiwa_constraint_terms_against_the_reference_urdf(golden, bias, dt):
+    """A9 pinned to a reference-held file: golden set G10 is the reference's own urdf/iiwa_1.urdf run through the generic
+    URDF evaluator (oracle/gen_golden.py urdf); the HIP callables must reproduce the constraint values, Jacobians and
+    bias terms the reference's formulas (iiwa_hit_atacom.py:70-139) give on those frames.
+    Tolerances: f64 1e-10; f32 3e-6 on values / Jacobian entries (O(1) m, 7 chained rotations at eps = 6e-8) and 2e-5
+    on the bias terms (products of two velocities up to ~2.4 rad/s each)."""
+    from rl_on_manifold_amd import constraint_terms
+    from test_oracle_urdf import expected_terms
+    g = golden('iiwa_urdf')
+    fun_e, J_e, b_e = expected_terms(g, bias)
+    fun, J, b = constraint_terms('iiwa', torch.tensor(g['q'], device=DEV, dtype=DT[dt]),
+                                 torch.tensor(g['dq'], device=DEV, dtype=DT[dt]), bias_mode=bias)
+    tol = (1e-10, 1e-10, 1e-10) if dt == 'f64' else (3e-6, 3e-6, 2e-5)
+    assert np.abs(fun.cpu().numpy() - fun_e).max() < tol[0]
+    assert np.abs(J.cpu().numpy() - J_e).max() < tol[1]
+    assert np.abs(b.cpu().numpy() - b_e).max() < tol[2]
+
+
 @pytest.mark.parametrize('lanes', [1, 2, 4])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 @pytest.mark.parametrize('name', ['circle', 'planar', 'iiwa'])
