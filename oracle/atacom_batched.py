@@ -93,7 +93,7 @@ def _larfg(alpha, x):
     return beta, v, tau
 
 
-def bidiag_solve_null(Jc, rhs, k):
+def bidiag_solve_null(Jc, rhs, k, cond=None):
     """For each Jc[b] (c x n, full row rank): x = Jc^+ rhs[b]  and the orthonormal null basis N[b]
     (n x k) = last k columns of P = G(1)...G(c) -- the basis LAPACK's SVD returns (nullspace.py)."""
     a = np.array(Jc, dtype=np.float64, copy=True)
@@ -118,10 +118,21 @@ def bidiag_solve_null(Jc, rhs, k):
             a[:, i + 1:, i + 1:] -= tauq[:, None, None] * uu[:, :, None] * w[:, None, :]
             wy = (uu * y[:, i + 1:]).sum(-1)
             y[:, i + 1:] -= (tauq * wy)[:, None] * uu
+    if cond is not None:
+        # conditioning of the solve: ratio of the extreme singular values of the bidiagonal factor (= those of Jc)
+        Bm = np.zeros((B, m, m))
+        ii = np.arange(m)
+        Bm[:, ii, ii] = d
+        if m > 1:
+            Bm[:, ii[1:], ii[:-1]] = e
+        sv = np.linalg.svd(Bm, compute_uv=False)
+        cond[:] = np.maximum(cond, sv[:, 0] / np.maximum(sv[:, -1], 1e-300))
     z = np.zeros((B, n))
+    dtol = np.abs(d).max(-1) * np.finfo(np.float64).eps * 8 * (m + 5)       # guarded solve, see nullspace.bidiag_pinv_apply
     for i in range(m):
         prev = e[:, i - 1] * z[:, i - 1] if i > 0 else 0.0
-        z[:, i] = (y[:, i] - prev) / d[:, i]
+        ok = np.abs(d[:, i]) > dtol
+        z[:, i] = np.where(ok, (y[:, i] - prev) / np.where(ok, d[:, i], 1.0), 0.0)
     X = np.zeros((B, n, k + 1))
     X[:, :, 0] = z
     X[:, np.arange(m, n), np.arange(1, k + 1)] = 1.0
@@ -132,8 +143,13 @@ def bidiag_solve_null(Jc, rhs, k):
     return X[:, :, 0], X[:, :, 1:]
 
 
-def rref_tol(N, tol):
-    """Batched null_space_coordinate.rref(N, row_vectors=False, tol) (lines 40-79)."""
+def rref_tol(N, tol, margin=None):
+    """Batched null_space_coordinate.rref(N, row_vectors=False, tol) (lines 40-79).
+    margin (optional, [B], updated in place with minimum): how far the DISCRETE decisions of the elimination were from
+    going the other way -- |p - tol| of every pivot-or-skip test (:56-63) and the gap between the largest and the
+    second largest candidate of every arg-max (:55).  A float32 evaluation of the same matrix can only take a different
+    branch where this margin is of the order of its rounding error; the parity tests use it to separate "arithmetic
+    error" from "the reference's own discontinuity"."""
     V = np.array(np.swapaxes(N, 1, 2), dtype=np.float64, copy=True)       # B x k x n
     B, m, n = V.shape
     i = np.zeros(B, dtype=np.int64)
@@ -147,6 +163,13 @@ def rref_tol(N, tol):
         col = np.where(rows >= i[:, None], col, -1.0)
         kk = np.argmax(col, axis=1)                       # first maximum, like np.argmax
         p = col[ar, kk]
+        if margin is not None:
+            second = col.copy()
+            second[ar, kk] = -1.0
+            gap = p - second.max(axis=1)                  # arg-max tie margin (inf-like when a single candidate is left)
+            gap = np.where(second.max(axis=1) < 0, np.inf, gap)
+            mg = np.minimum(np.abs(p - tol), np.where(p > tol, gap, np.inf))
+            margin[:] = np.where(active, np.minimum(margin, mg), margin)
         piv = active & (p > tol)
         skip = active & ~piv
         # negligible column: zero it from row i down
@@ -267,8 +290,8 @@ class BatchedAtacomEnv:
         if sp.mode == MODE_ERROR_CORRECTION:       # error_correction_wrapper.py:117-130
             x, _ = bidiag_solve_null(Jc, sp.Kc * c, sp.n_null)
             return np.concatenate([alpha, np.zeros((B, ng))], -1) - x
-        x, N = bidiag_solve_null(Jc, psi + sp.Kc * c, sp.n_null)
-        Nr = rref_tol(N, sp.rref_tol)
+        x, N = bidiag_solve_null(Jc, psi + sp.Kc * c, sp.n_null, getattr(self, 'cond_number', None))
+        Nr = rref_tol(N, sp.rref_tol, getattr(self, 'decision_margin', None))
         return -x + np.einsum('bnk,bk->bn', Nr, alpha)
 
     def acc_truncation(self, dq, ddq):
@@ -277,9 +300,33 @@ class BatchedAtacomEnv:
         lo = np.minimum(np.maximum(-sp.acc_max, -sp.Kq * (dq + sp.vel_max)), sp.acc_max)
         return np.clip(ddq, lo, up)
 
+    def track_margins(self, on=True):
+        """Per env step, record how close the step's discrete decisions came to flipping:
+        decision_margin [B] -- the rref pivot / arg-max tests of every sub-step (see rref_tol);
+        cond_number [B]     -- conditioning of the pseudo-inverse solve (sigma_max / sigma_min of J_c);
+        contact_margin [B]  -- the puck model's tests (contact distance, approach speed, rims, goal mouth, hit latch,
+                               absorbing thresholds), in metres / metres per second."""
+        if on:
+            self.decision_margin = np.full(self.B, np.inf)
+            self.contact_margin = np.full(self.B, np.inf)
+            self.cond_number = np.zeros(self.B)          # largest sigma_max / sigma_min of J_c over the sub-steps
+        else:
+            for k in ('decision_margin', 'contact_margin', 'cond_number'):
+                self.__dict__.pop(k, None)
+
+    def _cm(self, values, where=None):
+        cm = getattr(self, 'contact_margin', None)
+        if cm is not None:
+            v = np.abs(values)
+            cm[:] = np.minimum(cm, v if where is None else np.where(where, v, np.inf))
+
     def step(self, action):
         sp = self.spec
         nq = sp.dim_q
+        if hasattr(self, 'decision_margin'):
+            self.decision_margin[:] = np.inf
+            self.contact_margin[:] = np.inf
+            self.cond_number[:] = 0.0
         act = np.clip(np.asarray(action, dtype=np.float64), -1.0, 1.0)
         alpha = act * (sp.alpha_max if sp.mode == MODE_ATACOM else (sp.acc_max if sp.mode == MODE_ERROR_CORRECTION else 1.0))
         if sp.env_id == ENV_CIRCLE and sp.mode == MODE_TERMINATED:
@@ -344,19 +391,27 @@ class BatchedAtacomEnv:
         n = np.where((dist > 0)[:, None], d / safe[:, None], np.array([1.0, 0.0]))
         vrel = ((pk[:, 3:5] - mallet_vel) * n).sum(-1)
         imp = hit & (vrel < 0)
+        self._cm(dist - R)
+        self._cm(vrel, hit)
         pk[:, 3:5] = np.where(imp[:, None], pk[:, 3:5] - ((1 + E_MALLET) * vrel)[:, None] * n, pk[:, 3:5])
         pk[:, 0:2] = np.where(hit[:, None], mallet + n * R, pk[:, 0:2])
         ylim = TABLE_WIDTH / 2 - PUCK_RADIUS
         oy = np.abs(pk[:, 1]) > ylim
+        self._cm(np.abs(pk[:, 1]) - ylim)
+        self._cm(pk[:, 4], oy)
         sg = np.sign(pk[:, 1])
         pk[:, 1] = np.where(oy, sg * (2 * ylim - np.abs(pk[:, 1])), pk[:, 1])
         pk[:, 4] = np.where(oy & (pk[:, 4] * sg > 0), -E_RIM * pk[:, 4], pk[:, 4])
         xlim = TABLE_LENGTH / 2 - PUCK_RADIUS
         ox = (np.abs(pk[:, 0]) > xlim) & (np.abs(pk[:, 1]) >= GOAL_WIDTH)
+        self._cm(np.abs(pk[:, 0]) - xlim)
+        self._cm(np.abs(pk[:, 1]) - GOAL_WIDTH, np.abs(pk[:, 0]) > xlim)
+        self._cm(pk[:, 3], ox)
         sg = np.sign(pk[:, 0])
         pk[:, 0] = np.where(ox, sg * (2 * xlim - np.abs(pk[:, 0])), pk[:, 0])
         pk[:, 3] = np.where(ox & (pk[:, 3] * sg > 0), -E_RIM * pk[:, 3], pk[:, 3])
         v = np.hypot(pk[:, 3], pk[:, 4])
+        self._cm(v - 0.1, ~self.has_hit)
         new_hit = (~self.has_hit) & (v > 0.1)
         self.vel_hit_x = np.where(new_hit, pk[:, 3], self.vel_hit_x)
         self.has_hit |= new_hit
@@ -365,14 +420,20 @@ class BatchedAtacomEnv:
         sp = self.spec
         bnd = np.array([TABLE_LENGTH, TABLE_WIDTH]) / 2
         out = np.any(np.abs(self.puck[:, :2]) > bnd, -1)
-        out |= np.any(np.abs(mallet_xy_world(sp, self.q)) - bnd > 0.02, -1)
-        out |= self.has_hit & (np.hypot(self.puck[:, 3], self.puck[:, 4]) < 0.01)
+        mal = np.abs(mallet_xy_world(sp, self.q)) - bnd
+        out |= np.any(mal > 0.02, -1)
+        spd = np.hypot(self.puck[:, 3], self.puck[:, 4])
+        out |= self.has_hit & (spd < 0.01)
+        self._cm((np.abs(self.puck[:, :2]) - bnd).T[0]); self._cm((np.abs(self.puck[:, :2]) - bnd).T[1])
+        self._cm(mal[:, 0] - 0.02); self._cm(mal[:, 1] - 0.02)
+        self._cm(spd - 0.01, self.has_hit)
         return out
 
     def _reward(self, alpha, absorbing):
         sp = self.spec
         pp = self.puck[:, :2]
         goal = (pp[:, 0] - TABLE_LENGTH / 2 > 0) & (np.abs(pp[:, 1]) - GOAL_WIDTH < 0)
+        self._cm(np.abs(pp[:, 1]) - GOAL_WIDTH, absorbing & (pp[:, 0] - TABLE_LENGTH / 2 > 0))
         ee = mallet_xy_world(sp, self.q)
         d = pp - ee
         dist = np.sqrt((d * d).sum(-1))

@@ -126,6 +126,10 @@ def bidiag_pinv_apply(a, r):
         w = uu @ y[i + 1:]
         y[i + 1:] -= tau * uu * w
     z = np.zeros(n)
+    dtol = np.abs(d).max() * np.finfo(np.float64).eps * 8 * (m + 5)
     for i in range(m):
-        z[i] = (y[i] - (e[i - 1] * z[i - 1] if i > 0 else 0.0)) / d[i]
+        # rank handling of this build (DESIGN.md "Rank handling"): a pivot below 8 eps (M + 5) max|d| is treated as
+        # zero and its solution component dropped -- pinv_null's singular-value cutoff (:12-21) restated for the
+        # bidiagonal form; irrelevant for a full-rank matrix
+        z[i] = (y[i] - (e[i - 1] * z[i - 1] if i > 0 else 0.0)) / d[i] if abs(d[i]) > dtol else 0.0
     return _apply_P(G, z)

@@ -14,7 +14,7 @@ def __getattr__(name):
         from . import engine
         return getattr(engine, name)
     if name in ('CircleEnvAtacom', 'AirHockeyPlanarAtacom', 'AirHockeyIiwaAtacom', 'CircleEnvErrorCorrection',
-                'CircleEnvTerminated'):
+                'CircleEnvTerminated', 'VectorizedAtacomEnv'):
         from . import envs
         return getattr(envs, name)
     if name == 'RolloutCollector':

@@ -65,7 +65,8 @@ constexpr int kStatBlocks = 256;
 // time is flat while its waves still find a SIMD each (1024 SIMDs) and doubles beyond.  So: the widest mapping whose
 // waves fit -- quad up to 16384 envs (1024 waves), pair up to 32768, lane beyond.
 int pick_lanes(const atacom_config& c) {
-    if (c.lanes_per_env == 1 || c.lanes_per_env == 2 || c.lanes_per_env == 4) return c.lanes_per_env;
+    if (c.lanes_per_env == 1 || c.lanes_per_env == 2 || c.lanes_per_env == 4 || c.lanes_per_env == 8)
+        return c.lanes_per_env;
     if (c.dtype == ATACOM_F64) return 1;
     if (c.env_id == ATACOM_ENV_IIWA || c.env_id == ATACOM_ENV_PLANAR)      // iiwa: 30 / 40 / 52 us per step
         return c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1);
@@ -194,8 +195,9 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
     if (!ops) return fail(ATACOM_E_INVALID, "atacom_create: unknown env_id / dtype");
     if (cfg->batch <= 0 || cfg->substeps <= 0 || cfg->horizon <= 0 || !(cfg->dt > 0))
         return fail(ATACOM_E_INVALID, "atacom_create: batch, substeps, horizon and dt must be positive");
-    if (cfg->lanes_per_env != 0 && cfg->lanes_per_env != 1 && cfg->lanes_per_env != 2 && cfg->lanes_per_env != 4)
-        return fail(ATACOM_E_INVALID, "atacom_create: lanes_per_env must be 0 (auto), 1, 2 or 4");
+    if (cfg->lanes_per_env != 0 && cfg->lanes_per_env != 1 && cfg->lanes_per_env != 2 && cfg->lanes_per_env != 4 &&
+        cfg->lanes_per_env != 8)
+        return fail(ATACOM_E_INVALID, "atacom_create: lanes_per_env must be 0 (auto), 1, 2, 4 or 8");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(ATACOM_E_INVALID, "atacom_create: no such device");
@@ -373,8 +375,8 @@ int atacom_set_state(atacom_handle* h, const void* d_state, void* stream) {
 
 int atacom_nullspace(int32_t env_id, int32_t dtype, int32_t lanes_per_env, int32_t n, const void* d_Jc,
                      const void* d_rhs, double tol, void* d_x, void* d_null, void* d_rref, void* stream) {
-    if (lanes_per_env != 1 && lanes_per_env != 2 && lanes_per_env != 4)
-        return fail(ATACOM_E_INVALID, "atacom_nullspace: lanes_per_env must be 1, 2 or 4");
+    if (lanes_per_env != 1 && lanes_per_env != 2 && lanes_per_env != 4 && lanes_per_env != 8)
+        return fail(ATACOM_E_INVALID, "atacom_nullspace: lanes_per_env must be 1, 2, 4 or 8");
     const atacom::EnvOps* ops = get_ops(env_id, dtype);
     if (!ops) return fail(ATACOM_E_INVALID, "atacom_nullspace: unknown env_id / dtype");
     if (n <= 0 || !d_Jc) return fail(ATACOM_E_INVALID, "atacom_nullspace: n must be positive and d_Jc non-null");

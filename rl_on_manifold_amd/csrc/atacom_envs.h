@@ -261,6 +261,7 @@ __device__ __forceinline__ void constraint_terms(Iiwa, const Params<T>& P, const
                                                  T (&fun)[12], T (&J)[12][6], T (&bst)[12]) {
     IiwaKin<T> k;
     iiwa_fk(q, k);
+    ATACOM_MARK("PRE_jac");
     T Je[3][6], J4[3][6], J7[3][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -278,6 +279,7 @@ __device__ __forceinline__ void constraint_terms(Iiwa, const Params<T>& P, const
             J4[0][i] = J4[1][i] = J4[2][i] = T(0);
         }
     }
+    ATACOM_MARK("PRE_bias");
     T ae[3], a4[3], a7[3];
     frame_bias<T, 6>(k, k.pe, Je, dq, P.bias_mode, ae);
     frame_bias<T, 4>(k, k.p4, J4, dq, P.bias_mode, a4);

@@ -225,13 +225,17 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
     T m0x = T(0), m0y = T(0);   // mallet position at the start of the env step
     T A[NC][NQ], yb[NC];       // yb = psi + Kc c0: the slack-independent part of the right-hand side (one value
                                // per row carried over the sub-steps instead of two)
-    constexpr int SQ = (NN + LANES - 1) / LANES;
-    T Aq[NC][SQ];              // LANES > 1: this lane's columns of [K J | 0]
+    constexpr int LGC = LANES > 1 ? LANES : 4;                  // lanes per environment of the group solver
+    constexpr int SQ = split_slots(NN, LGC);
+    T Aq[NC][SQ];              // LANES > 1: this lane's columns of [K J | 0] (column c >= 1 -> lane (c-1) % LANES,
+                               // slot (c-1) / LANES; column 0 is replicated and read from A directly, atacom_quad.h)
     auto prepare = [&](int sub) {
 #pragma unroll
             for (int i = 0; i < NQ; ++i) { qc[i] = st.q[i]; dqc[i] = st.dq[i]; }
             T fun[NC], J[NC][NQ], bst[NC];
+            ATACOM_MARK("PRE_terms");
             constraint_terms(E{}, P, qc, dqc, fun, J, bst);
+            ATACOM_MARK("PRE_assemble");
             if (E::PUCK && sub == 0) {
                 // mallet (= tip) xy at the start of the step, recovered from the table constraints
                 // g1 = -x - bx, g3 = y - by  (rows NF, NF+2)
@@ -252,6 +256,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 const T c0 = num<T>::fma(P.K[r], jdq, fun[r]);       // constraints.py:33-37
                 yb[r] = (E::MODE == 1) ? P.Kc[r] * c0 : num<T>::fma(P.Kc[r], c0, psi);   // E: no drift term (:127)
             }
+            ATACOM_MARK("PRE_blend");
             if (LANES > 1) {
                 // this lane's columns of K J: a one-hot blend over the lane group (exact: the mask is 0 / 1 and the
                 // entries carry no -0 after the fma above).  Written as arithmetic on purpose -- a `lq == l ? ... : ...`
@@ -266,8 +271,10 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                     for (int sl = 0; sl < SQ; ++sl) {
                         T v = T(0);
 #pragma unroll
-                        for (int l = 0; l < LANES; ++l)
-                            if (LANES * sl + l < NQ) v = num<T>::fma(oh[l], A[r][LANES * sl + l < NQ ? LANES * sl + l : 0], v);
+                        for (int l = 0; l < LANES; ++l) {
+                            const int c = LANES * sl + l + 1;
+                            if (c < NQ) v = num<T>::fma(oh[l], A[r][c < NQ ? c : 0], v);
+                        }
                         Aq[r][sl] = v;
                     }
             }
@@ -281,6 +288,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
             if (sub > 0) prepare(sub);
         }
         // J_c = [[K_f J_f, 0], [K_g J_g, diag(s)]],  rhs = psi + K_c c     (atacom.py:151-165,183-196)
+        ATACOM_MARK("SUB_begin");
         T mu[NN], y[NC];
 #pragma unroll
         for (int r = 0; r < NC; ++r) {
@@ -311,32 +319,36 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 for (int n = 0; n < NN; ++n) mu[n] = nmu[n] - x[n];           // atacom.py:130-133
             }
         } else {
-            constexpr int LG = LANES > 1 ? LANES : 4;        // lanes per environment (this branch: 2 or 4)
-            constexpr int S = (NN + LG - 1) / LG;
+            constexpr int LG = LGC;                          // lanes per environment (this branch: 2, 4 or 8)
+            constexpr int S = SQ;
             constexpr int ND = NN - NC;
-            T x[S], nb[S][ND], nmu[S];
+            T x0, x[S], nb0[ND], nb[S][ND], nmu0, nmu[S];
             T alphaq[ND];
 #pragma unroll
             for (int k = 0; k < ND; ++k) alphaq[k] = alpha[k < NK ? k : 0];
             // this lane's columns: the K J block was split once per step (Aq), the slack diagonal entry of
-            // row r sits in column NQ + r - NF, i.e. slot (NQ+r-NF)/LG of lane (NQ+r-NF)%LG
+            // row r sits in column c = NQ + r - NF, i.e. slot (c-1)/LG of lane (c-1)%LG
             auto aget = [&](auto rc, auto sc) -> T {
                 constexpr int r = decltype(rc)::value, sl = decltype(sc)::value;
                 const T base = Aq[r][sl];
                 if constexpr (r >= NF) {
                     constexpr int c = NQ + r - NF;
-                    if constexpr (c / LG == sl) return (lq == c % LG) ? st.s[r - NF] : base;
+                    if constexpr ((c - 1) / LG == sl) return (lq == (c - 1) % LG) ? st.s[r - NF] : base;
                 }
                 return base;
             };
+            auto a0get = [&](auto rc) -> T { return A[decltype(rc)::value][0]; };      // NQ >= 1: never a slack column
             auto yget = [&](auto rc) -> T { return y[decltype(rc)::value]; };
-            bidiag_solve_null_quad<T, NC, NN, LG>(aget, yget, x, nb, lq);
-            rref_apply_quad<T, NN, ND, LG>(nb, alphaq, P.rref_tol, nmu, lq);
-            static_for<0, NN>([&](auto nc) {                        // gather mu back to every lane of the group
+            bidiag_solve_null_quad<T, NC, NN, LG>(aget, a0get, yget, x0, x, nb0, nb, lq);
+            rref_apply_quad<T, NN, ND, LG>(nb0, nb, alphaq, P.rref_tol, nmu0, nmu, lq);
+            ATACOM_MARK("MU_gather");
+            mu[0] = nmu0 - x0;
+            static_for<1, NN>([&](auto nc) {                        // gather mu back to every lane of the group
                 constexpr int n = decltype(nc)::value;
-                mu[n] = qbcast<n % LG, LG>(nmu[n / LG] - x[n / LG]);
+                mu[n] = qbcast<(n - 1) % LG, LG>(nmu[(n - 1) / LG] - x[(n - 1) / LG]);
             });
         }
+        ATACOM_MARK("SUB_integrate");
 #pragma unroll
         for (int g = 0; g < NG; ++g) st.s[g] = num<T>::fma(mu[NQ + g], P.dt, st.s[g]);   // :135
         T ddq[NQ];
@@ -365,6 +377,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
             }
         }
     }
+    ATACOM_MARK("POST_fk");
     if (E::ID == 0) {
         const T dx = T(1) - st.q[0];
         out.reward = num<T>::exp(-num<T>::sqrt(num<T>::fma(dx, dx, st.q[1] * st.q[1])));   // circle_base.py:65
@@ -375,6 +388,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
         // ---- puck (row N1): the arm is kinematic w.r.t. the puck, so the puck's sub-steps run after the arm's,
         // against a mallet moving uniformly from (m0x, m0y) to mxy over the env step.  Frictionless disc,
         // impulse + push-out at the mallet, elastic rims, open goal mouths (env_hitting.py:44-45).
+        ATACOM_MARK("POST_puck");
         {
             const T inv_n = num<T>::rcp((T)P.substeps);
             const T ux = (mxy[0] - m0x) * inv_n / P.dt, uy = (mxy[1] - m0y) * inv_n / P.dt;
@@ -419,6 +433,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 st.has_hit = new_hit ? 1 : st.has_hit;
             }
         }
+        ATACOM_MARK("POST_reward");
         // absorbing: env_base.py:182-194 + env_hitting.py:71-78
         const T pv2 = num<T>::fma(st.puck[3], st.puck[3], st.puck[4] * st.puck[4]);
         bool ab = (num<T>::abs(st.puck[0]) > P.table_hx) || (num<T>::abs(st.puck[1]) > P.table_hy);
@@ -478,6 +493,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     for (int k = 0; k < E::NK; ++k) act[k] = action[(size_t)b * E::NK + k];
     StepOut<T> out;
     env_step<T, E, LANES, HOLD>(P, st, act, out, lq);
+    ATACOM_MARK("STORE");
     if (lq != 0) return;                       // the four lanes hold identical results; lane 0 writes
     write_obs<T, E>(P, st, obs + (size_t)b * E::OBS);
     reward[b] = out.reward;
@@ -852,21 +868,29 @@ template <typename T, typename E, int LN>
 __global__ void __launch_bounds__(WAVE) k_nullspace_quad(int n, const T* __restrict__ Jc, const T* __restrict__ rhs,
                                                          T tol, T* __restrict__ xo, T* __restrict__ nullo,
                                                          T* __restrict__ rrefo) {
-    constexpr int NC = E::NC, NN = E::NN, NK = E::NN - E::NC, S = (NN + LN - 1) / LN;
+    constexpr int NC = E::NC, NN = E::NN, NK = E::NN - E::NC, S = split_slots(NN, LN);
     const int gt = blockIdx.x * WAVE + threadIdx.x;
     const int b = gt / LN, lq = gt % LN;
     if (b >= n) return;
-    T x[S], nb[S][NK];
+    T x0, x[S], nb0[NK], nb[S][NK];
     auto aget = [&](auto rc, auto sc) -> T {
         constexpr int r = decltype(rc)::value, sl = decltype(sc)::value;
-        const int c = LN * sl + lq;
+        const int c = LN * sl + lq + 1;
         return (c < NN) ? Jc[((size_t)b * NC + r) * NN + (c < NN ? c : 0)] : T(0);
     };
+    auto a0get = [&](auto rc) -> T { return Jc[((size_t)b * NC + decltype(rc)::value) * NN]; };
     auto yget = [&](auto rc) -> T { return rhs ? rhs[(size_t)b * NC + decltype(rc)::value] : T(0); };
-    bidiag_solve_null_quad<T, NC, NN, LN>(aget, yget, x, nb, lq);
+    bidiag_solve_null_quad<T, NC, NN, LN>(aget, a0get, yget, x0, x, nb0, nb, lq);
+    if (lq == 0) {
+        if (xo) xo[(size_t)b * NN] = x0;
+        if (nullo) {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) nullo[(size_t)b * NN * NK + k] = nb0[k];
+        }
+    }
 #pragma unroll
     for (int sl = 0; sl < S; ++sl) {
-        const int c = LN * sl + lq;
+        const int c = LN * sl + lq + 1;
         if (c < NN) {
             if (xo) xo[(size_t)b * NN + c] = x[sl];
             if (nullo) {
@@ -878,17 +902,20 @@ __global__ void __launch_bounds__(WAVE) k_nullspace_quad(int n, const T* __restr
     if (rrefo) {
 #pragma unroll 1
         for (int k = 0; k < NK; ++k) {
-            T nb2[S][NK], alpha[NK], col[S];
+            T nb2[S][NK], nb02[NK], alpha[NK], col[S], col0;
+#pragma unroll
+            for (int j = 0; j < NK; ++j) nb02[j] = nb0[j];
 #pragma unroll
             for (int sl = 0; sl < S; ++sl)
 #pragma unroll
                 for (int j = 0; j < NK; ++j) nb2[sl][j] = nb[sl][j];
 #pragma unroll
             for (int j = 0; j < NK; ++j) alpha[j] = (j == k) ? T(1) : T(0);
-            rref_apply_quad<T, NN, NK, LN>(nb2, alpha, tol, col, lq);
+            rref_apply_quad<T, NN, NK, LN>(nb02, nb2, alpha, tol, col0, col, lq);
+            if (lq == 0) rrefo[(size_t)b * NN * NK + k] = col0;
 #pragma unroll
             for (int sl = 0; sl < S; ++sl) {
-                const int c = LN * sl + lq;
+                const int c = LN * sl + lq + 1;
                 if (c < NN) rrefo[((size_t)b * NN + c) * NK + k] = col[sl];
             }
         }

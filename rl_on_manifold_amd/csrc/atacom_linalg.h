@@ -20,6 +20,14 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+// instruction-count profiling aid: -DATACOM_MARKS puts named comment lines into the ISA (and pins the schedule at
+// them); build/isa tooling splits the kernel body at the marks.  Off in the product build.
+#ifdef ATACOM_MARKS
+#define ATACOM_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MARK " name); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ATACOM_MARK(name) ((void)0)
+#endif
+
 namespace atacom {
 
 template <typename T> struct num;
@@ -109,18 +117,61 @@ template <typename T> __device__ __forceinline__ vec2<T> fma2(vec2<T> a, vec2<T>
     return __builtin_elementwise_fma(a, b, c);
 }
 
-// LAPACK dlarfg on (alpha, x[0..L)) given ss = sum x^2: H = I - tau [1;v][1;v]^T, H [alpha;x] = [beta;0].
-// Returns the scale 1/(alpha-beta) to apply to x (0 when x == 0, i.e. H = I), writes beta and tau.
+// Householder reflector of LAPACK's dlarfg on (alpha, x[0..L)) given ss = sum x^2:  H = I - tau [1;v][1;v]^T,
+// H [alpha;x] = [beta;0],  beta = -sign(alpha) ||[alpha;x]||.  Returns the scale 1/(alpha-beta) to apply to x, writes
+// beta and tau.
+// Two departures from dlarfg's special cases, both branch-free (the old form spent 5 selects per reflector on them):
+//   * x == 0, alpha != 0: dlarfg returns H = I (tau = 0, beta = alpha); this form returns the reflection through
+//     alpha's axis (tau = 2, beta = -alpha, v = 0).  The two differ by the sign of ONE vector of the row-space basis
+//     (P -> P D_i, Q -> Q D_i with D_i = diag(.., -1, ..)), which cancels in  x = P B^-1 Q^T y  and never reaches the
+//     null basis P[:, M:] (column i < M of P is not a null vector) -- DESIGN.md section 3;
+//   * the all-zero vector (rank-deficient matrix): tau = 0, v = 0, beta = -+TINY, i.e. H = I with a pivot the guarded
+//     bidiagonal solve then treats as zero -- no NaN / Inf is ever produced here.
+template <typename T> struct tiny_of;
+template <> struct tiny_of<float> { static constexpr float value = 1e-30f; };
+template <> struct tiny_of<double> { static constexpr double value = 1e-280; };
 template <typename T>
 __device__ __forceinline__ T larfg_scale(T alpha, T ss, T& beta, T& tau) {
+#ifdef ATACOM_LARFG_GUARDED        // A/B switch: dlarfg's special cases as five selects (the round-1 form)
     const bool nz = ss != T(0);
-    const T nrm = num<T>::sqrt(num<T>::fma(alpha, alpha, ss));
-    const T b = -num<T>::copysign(nrm, alpha);
-    beta = nz ? b : alpha;
-    const T safe_b = nz ? b : T(1);
-    tau = nz ? num<T>::div(b - alpha, safe_b) : T(0);
-    const T den = nz ? (alpha - b) : T(1);
+    const T nrm0 = num<T>::sqrt(num<T>::fma(alpha, alpha, ss));
+    const T b0 = -num<T>::copysign(nrm0, alpha);
+    beta = nz ? b0 : alpha;
+    const T safe_b = nz ? b0 : T(1);
+    tau = nz ? num<T>::div(b0 - alpha, safe_b) : T(0);
+    const T den = nz ? (alpha - b0) : T(1);
     return nz ? num<T>::rcp(den) : T(0);
+#endif
+    const T nrm = num<T>::sqrt(num<T>::fma(alpha, alpha, ss));
+    const T b = num<T>::copysign(num<T>::max(nrm, tiny_of<T>::value), -alpha);   // = -sign(alpha) max(nrm, TINY)
+    const T dm = b - alpha;                                                       // |dm| = |b| + |alpha| >= TINY
+    beta = b;
+    const T t = dm * num<T>::rcp(b);
+    tau = (nrm > T(0)) ? t : T(0);
+    return -num<T>::rcp(dm);
+}
+
+// z = B^+ y for the lower bidiagonal B (d on the diagonal, e below it) by forward substitution, with the reference's
+// rank handling restated for the bidiagonal form: pinv_null drops singular values below eps * max(M, N) * sigma_max
+// (null_space_coordinate.py:12-21); here a pivot |d_i| <= 8 eps (M + 5) max|d| is treated as zero -- its component of the
+// solution is dropped (z_i = 0) instead of dividing by it.  For a full-rank matrix this changes nothing; for a
+// rank-deficient one it keeps every downstream value finite (DESIGN.md "Rank handling").
+template <typename T> struct eps_of;
+template <> struct eps_of<float> { static constexpr float value = 1.1920929e-7f; };
+template <> struct eps_of<double> { static constexpr double value = 2.220446049250313e-16; };
+template <typename T, int M, typename YG>
+__device__ __forceinline__ void bidiag_forward_solve(const T (&d)[M], const T (&e)[M], YG&& yat, T (&z)[M]) {
+    T dmax = num<T>::abs(d[0]);
+#pragma unroll
+    for (int i = 1; i < M; ++i) dmax = num<T>::max(dmax, num<T>::abs(d[i]));
+    const T dtol = dmax * (eps_of<T>::value * T(8 * (M + 5)));  // N <= M + 5 for every shape of this library; x8: a
+                                                                // duplicated row leaves a pivot of a few eps, not 0
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        const T rd = (num<T>::abs(d[i]) > dtol) ? num<T>::rcp(d[i]) : T(0);
+        const T rhs = (i == 0) ? yat(0) : num<T>::fma(-e[i > 0 ? i - 1 : 0], z[i > 0 ? i - 1 : 0], yat(i));
+        z[i] = rhs * rd;
+    }
 }
 
 // A: M x N (row i, col j), full row rank; y: right-hand side (length M) -- both handed over as generators
@@ -217,9 +268,7 @@ __device__ __forceinline__ void bidiag_solve_null(AF&& aget, YF&& yget, T (&x)[N
     });
     // ---- z = B^{-1} (Q^T y), B lower bidiagonal (d on the diagonal, e below it)
     T z[M];
-    z[0] = num<T>::div(y2[0].x, d[0]);
-#pragma unroll
-    for (int i = 1; i < M; ++i) z[i] = num<T>::div(num<T>::fma(-e[i - 1], z[i - 1], y2[i / 2][i % 2]), d[i]);
+    bidiag_forward_solve<T, M>(d, e, [&](int i) { return y2[i / 2][i % 2]; }, z);
     V2 nx[N][KP];
 #pragma unroll
     for (int c = 0; c < N; ++c) {

@@ -49,7 +49,10 @@ struct Ops {
     }
     static void step(const atacom_config& c, int lanes, void* f, int* ip, const void* act, void* obs, void* rew,
                      uint8_t* ab, uint8_t* last, hipStream_t s) {
-        if (lanes == 4) {
+        if (lanes == 8) {
+            if (c.hold_q) launch_step<8, true>(c, f, ip, act, obs, rew, ab, last, s);
+            else launch_step<8, false>(c, f, ip, act, obs, rew, ab, last, s);
+        } else if (lanes == 4) {
             if (c.hold_q) launch_step<4, true>(c, f, ip, act, obs, rew, ab, last, s);
             else launch_step<4, false>(c, f, ip, act, obs, rew, ab, last, s);
         } else if (lanes == 2) {
@@ -70,7 +73,10 @@ struct Ops {
     }
     static void rollout(const atacom_config& c, int lanes, int n_steps, void* f, int* ip, const void* acts, void* obs,
                         void* nobs, void* rew, uint8_t* ab, uint8_t* last, void* rec, int rec_ld, hipStream_t s) {
-        if (lanes == 4) {
+        if (lanes == 8) {
+            if (c.hold_q) launch_rollout<8, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
+            else launch_rollout<8, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
+        } else if (lanes == 4) {
             if (c.hold_q) launch_rollout<4, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
             else launch_rollout<4, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
         } else if (lanes == 2) {
@@ -110,7 +116,7 @@ struct Ops {
         a.log_std_min = (T)net.log_std_min; a.log_std_max = (T)net.log_std_max; a.squash = net.squash;
         a.n_in = net.n_in; a.n_out = net.n_out; a.activation = net.activation;
         if constexpr (E::ID != 0) {
-            if (lanes == 4) {
+            if (lanes >= 4) {          // the policy kernels have no 8-lane form (their GEMM blocks are 16 envs = quads)
                 if (c.hold_q) launch_mlp<4, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
                 else launch_mlp<4, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
             } else if (lanes == 2) {
@@ -149,7 +155,10 @@ struct Ops {
     }
     static void nullspace(int lanes, int n, const void* Jc, const void* rhs, double tol, void* x, void* nullb,
                           void* rref, hipStream_t s) {
-        if (lanes == 4)
+        if (lanes == 8)
+            hipLaunchKernelGGL((k_nullspace_quad<T, E, 8>), dim3(nblk(n * 8, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,
+                               (const T*)rhs, (T)tol, (T*)x, (T*)nullb, (T*)rref);
+        else if (lanes == 4)
             hipLaunchKernelGGL((k_nullspace_quad<T, E, 4>), dim3(nblk(n * 4, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,
                                (const T*)rhs, (T)tol, (T*)x, (T*)nullb, (T*)rref);
         else if (lanes == 2)

@@ -89,9 +89,28 @@ class BatchedAtacomEnv:
         self._reward = torch.empty((B,), device=self.device, dtype=dtype)
         self._absorbing = torch.empty((B,), device=self.device, dtype=torch.uint8)
         self._last = torch.empty((B,), device=self.device, dtype=torch.uint8)
-        inf = np.full(D, np.inf)
-        self._mdp_info = MDPInfo(Box(-inf, inf), Box(-np.ones(k), np.ones(k)), cfg.gamma, cfg.horizon)   # atacom.py:50-51
+        lo, hi = self.observation_bounds(self.env_id, cfg)
+        self._mdp_info = MDPInfo(Box(lo, hi), Box(-np.ones(k), np.ones(k)), cfg.gamma, cfg.horizon)   # atacom.py:50-51
         self.reset()
+
+    @staticmethod
+    def observation_bounds(env_id, cfg):
+        """Bounds of the observation space exactly as the reference's MDPInfo carries them, so that a caller's
+        `MinMaxPreprocessor(mdp_info=mdp.info)` (examples/iiwa_air_hockey_exp.py:32) normalises the same entries:
+          circle : Box(-inf, inf) on all four entries (circle_base.py:21-22);
+          iiwa   : env_single.py:69-80 -- puck x, y, yaw in [-1, 1] x [-0.5, 0.5] x [-pi, pi], puck velocities unbounded
+                   (a PyBullet body velocity has no limit), joint positions within the URDF position limits, joint
+                   velocities within the URDF velocity limits (iiwa_1.urdf:74,112,149,186,223,260);
+          planar : the same construction with the 3R arm's limits (the reference takes these from MushroomRL's
+                   AirHockeyHit, which is not in the tree: an analogue, not a pinned copy)."""
+        if env_id in (_lib.ENV_CIRCLE, _lib.ENV_CIRCLE_EC, _lib.ENV_CIRCLE_T):
+            inf = np.full(4, np.inf)
+            return -inf, inf
+        nq = 3 if env_id == _lib.ENV_PLANAR else 6
+        pos = np.array(list(cfg.pos_limit)[:nq])
+        vel = np.array(list(cfg.vel_max)[:nq])
+        hi = np.concatenate([[1.0, 0.5, np.pi], np.full(3, np.inf), pos, vel])
+        return -hi, hi
 
     # ------------------------------------------------------------------ reference surface
     @property

@@ -151,3 +151,73 @@ class AirHockeyIiwaAtacom(_AirHockeyFacade):
                  action_penalty=1e-3, device='cuda:0', dtype=torch.float32):
         self._init_common(task, gamma, horizon, timestep, n_intermediate_steps, env_noise, obs_noise, obs_delay,
                           Kc, random_init, action_penalty, device, dtype)
+
+
+class VectorizedAtacomEnv:
+    """`n_envs` ATACOM environments behind ONE surface, for a vectorised Core: the method names and argument order of
+    MushroomRL 2's `VectorizedEnvironment` (`reset_all(env_mask, state)`, `step_all(env_mask, action)`, `number`,
+    `info`), torch tensors on the device in and out -- no per-step host synchronisation, unlike the batch-1 facades
+    above, which exist for unchanged MushroomRL-1 scripts (SURVEY.md section 8b "batched surface").
+
+      env = VectorizedAtacomEnv('iiwa', n_envs=8192)
+      obs, _ = env.reset_all(mask_all)
+      obs, reward, absorbing, info = env.step_all(mask_all, actions)     # info['last'] marks finished episodes
+
+    Environments whose mask entry is False keep their state (a vector Core masks out the environments that have already
+    delivered their episodes); the engine steps the whole batch in one launch, so a partial mask costs a state
+    save / restore around the launch."""
+
+    def __init__(self, env, n_envs, device='cuda:0', dtype=torch.float32, **engine_kwargs):
+        self._engine = BatchedAtacomEnv(env, n_envs, device=device, dtype=dtype, **engine_kwargs)
+        self.number = int(n_envs)
+        self.dims = self._engine.dims
+        self._obs = self._engine.reset()
+
+    @property
+    def info(self):
+        return self._engine.info
+
+    @property
+    def engine(self):
+        return self._engine
+
+    def seed(self, seed):
+        self._engine.seed(seed)
+
+    def render_all(self, env_mask=None, record=False):
+        pass
+
+    def stop(self):
+        self._engine.stop()
+
+    def _mask(self, env_mask):
+        if env_mask is None:
+            return None
+        m = torch.as_tensor(env_mask, device=self._engine.device).bool()
+        return None if bool(m.all()) else m
+
+    def reset_all(self, env_mask=None, state=None):
+        """Reset the masked environments (all if None); returns (observations [n_envs, D], {})."""
+        m = self._mask(env_mask)
+        self._obs = self._engine.reset(mask=None if m is None else m.to(torch.uint8), state=state)
+        return self._obs, {}
+
+    def step_all(self, env_mask, action):
+        """One env step of the masked environments.  action [n_envs, k] (rows of masked-out environments are ignored)."""
+        m = self._mask(env_mask)
+        eng = self._engine
+        if m is None:
+            obs, r, ab, info = eng.step(action)
+        else:
+            saved = eng.get_state()
+            obs, r, ab, info = eng.step(action)
+            eng.set_state(torch.where(m[:, None], eng.get_state(), saved))
+            obs = torch.where(m[:, None], obs, self._obs)
+            r = torch.where(m, r, torch.zeros_like(r))
+            ab = ab & m
+            info = {'last': info['last'] & m}
+        self._obs = obs
+        return obs, r, ab, info
+
+    def get_constraints_logs(self):
+        return self._engine.get_constraints_logs()

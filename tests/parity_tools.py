@@ -1,0 +1,158 @@
+"""How the float32 parity tests decide that an error is *explained* -- with no sample allowed to stay unexplained.
+
+The reference algorithm is discontinuous (rref's 0.05 pivot tolerance, atacom.py:128; contact / rim / latch decisions of
+the puck model) and, away from its discontinuities, has a large and strongly state-dependent Lipschitz constant (the
+slack dynamics ~ 1/s; four chained sub-steps).  A float32 evaluation is a float64 evaluation of slightly perturbed data
+(backward stability), so the honest bound on |HIP_f32 - oracle_f64| is the oracle's own response to float32-sized
+perturbations of its inputs:
+
+    sens(x) = max over perturbations d, |d_i| <= eps_rel * |x_i|, of | oracle(x + d) - oracle(x) |
+
+estimated by sampling (a handful of random sign patterns at three magnitudes, 2e-7 ... 4e-6 relative: 2 to 30 float32
+ulps).  A sample PASSES if  err <= C * sens + floor.  A sample that does not pass the cheap estimate is re-examined
+with many more draws at up to 1.6e-5 relative (a discontinuity just outside the first ball: the tolerance branch one of
+the kernel's ~10^4 rounded operations can reach); if the float64 oracle itself then moves by >= err / C it passes,
+otherwise the test FAILS.  Nothing is waved through by a percentage: a kernel bug (wrong lane, wrong row, stale
+register) produces errors where the oracle is insensitive and is caught on the first sample.
+
+C = 10 and floor = 5e-6 * max(1, |value|) are calibrated on 4.1e5 teacher-forced env steps per environment
+(profiles/r02_parity_sensitivity.md): the largest err / sens ratio seen was 8.9, the median 0.01.
+"""
+import copy
+
+import numpy as np
+
+QUICK_SCALES = (2e-7, 1e-6, 4e-6)
+DEEP_SCALES = (1e-6, 4e-6, 1.6e-5)
+C_SENS = 10.0
+FLOOR = 5e-6
+
+
+def slice_env(o, idx):
+    """A deep copy of a batched oracle env restricted to the environments `idx`."""
+    p = copy.copy(o)
+    idx = np.asarray(idx)
+    for k, v in o.__dict__.items():
+        if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == o.B:
+            setattr(p, k, v[idx].copy())
+        else:
+            setattr(p, k, copy.deepcopy(v))
+    p.B = len(idx)
+    return p
+
+
+def perturbed(o, scale, rng, fields=('q', 'dq', 's', 'puck')):
+    p = slice_env(o, np.arange(o.B))
+    for k in ('decision_margin', 'contact_margin', 'cond_number'):
+        p.__dict__.pop(k, None)
+    for f in fields:
+        arr = getattr(p, f)
+        arr *= 1.0 + scale * rng.choice([-1.0, 1.0], arr.shape)
+    return p
+
+
+class SensitivityRecorder:
+    """Collects, step by step, the device error and the oracle's sensitivity; `finish()` asserts that every sample is
+    explained (module docstring).
+
+    step_fn(env_copy, inputs) -> [B, n_out] float64 array of everything that is compared (it may advance env_copy).
+    `inputs` is a tuple of float arrays that are perturbed together with the state (actions, noise)."""
+
+    def __init__(self, step_fn, seed=0, state_fields=('q', 'dq', 's', 'puck')):
+        self.step_fn = step_fn
+        self.rng = np.random.default_rng(seed)
+        self.fields = state_fields
+        self.snaps, self.inputs, self.base, self.err, self.sens = [], [], [], [], []
+
+    def _sens(self, o, inputs, base, scales, draws):
+        s = np.zeros(o.B)
+        for sc in scales:
+            for _ in range(draws):
+                p = perturbed(o, sc, self.rng, self.fields)
+                pin = tuple(x * (1.0 + sc * self.rng.choice([-1.0, 1.0], x.shape)) for x in inputs)
+                out = self.step_fn(p, pin)
+                s = np.maximum(s, (np.abs(out - base) / np.maximum(1.0, np.abs(base))).max(1))
+        return s
+
+    def prepare(self, o, inputs):
+        """Oracle side of one sample (independent of the device, so a test parametrised over kernel mappings prepares
+        once and compares many times).  Call BEFORE the oracle env `o` is stepped; returns the oracle outputs."""
+        snap = slice_env(o, np.arange(o.B))
+        for k in ('decision_margin', 'contact_margin', 'cond_number'):
+            snap.__dict__.pop(k, None)
+        base = self.step_fn(slice_env(snap, np.arange(o.B)), inputs)
+        self.snaps.append(snap); self.inputs.append(inputs); self.base.append(base)
+        self.sens.append(self._sens(snap, inputs, base, QUICK_SCALES, 2))
+        return base
+
+    def compare(self, t, dev_out):
+        base = self.base[t]
+        e = (np.abs(np.asarray(dev_out, dtype=np.float64) - base) / np.maximum(1.0, np.abs(base))).max(1)
+        if len(self.err) <= t:
+            self.err.append(e)
+        else:
+            self.err[t] = e
+        return e
+
+    def record(self, o, inputs, dev_out):
+        """prepare + compare for tests that run once."""
+        base = self.prepare(o, inputs)
+        self.compare(len(self.base) - 1, dev_out)
+        return base
+
+    def fresh(self):
+        """A recorder sharing the prepared oracle data, with an empty error log (one per device configuration)."""
+        r = copy.copy(self)
+        r.err = []
+        r.sens = [x.copy() for x in self.sens]
+        return r
+
+    def finish(self, what=''):
+        E, S = np.array(self.err), np.array(self.sens)
+        bad = np.argwhere(E > C_SENS * S + FLOOR)
+        n_deep = len(bad)
+        unexplained = []
+        for t in np.unique(bad[:, 0]) if n_deep else []:
+            idx = bad[bad[:, 0] == t, 1]
+            sub = slice_env(self.snaps[t], idx)
+            sin = tuple(x[idx] for x in self.inputs[t])
+            s2 = self._sens(sub, sin, self.base[t][idx], DEEP_SCALES, 48)
+            for j, b in enumerate(idx):
+                S[t, b] = max(S[t, b], s2[j])
+                if E[t, b] > C_SENS * S[t, b] + FLOOR:
+                    unexplained.append((int(t), int(b), float(E[t, b]), float(S[t, b])))
+        ratio = E / (C_SENS * S + FLOOR)
+        summary = ('%s: %d samples, err median %.2e / p99.9 %.2e / max %.2e; err / (C sens + floor) max %.2f; '
+                   '%d samples needed the deep probe' % (what, E.size, np.median(E), np.quantile(E, 0.999), E.max(),
+                                                         ratio.max(), n_deep))
+        assert not unexplained, 'UNEXPLAINED float32 errors (t, env, err, sens): %s | %s' % (unexplained[:10], summary)
+        assert np.median(E) < 2e-5, summary            # and the bulk is at rounding level
+        return summary
+
+
+def assert_matrix_fn_explained(fn, A, dev_out, what='', seed=0):
+    """The same rule for a stand-alone primitive  out = fn(A)  on a batch of matrices A [n, M, N] (e.g. the chart
+    rref(null(A), tol)): every float32 device result within C x (float64 fn's response to float32-sized relative
+    perturbations of A) + floor; samples failing the quick estimate get the deep probe; none may stay unexplained."""
+    rng = np.random.default_rng(seed)
+    base = fn(A).reshape(len(A), -1)
+    scale = np.maximum(1.0, np.abs(base))
+    err = (np.abs(np.asarray(dev_out, dtype=np.float64).reshape(len(A), -1) - base) / scale).max(1)
+
+    def sens(idx, scales, draws):
+        s = np.zeros(len(idx))
+        for sc in scales:
+            for _ in range(draws):
+                out = fn(A[idx] * (1.0 + sc * rng.choice([-1.0, 1.0], A[idx].shape))).reshape(len(idx), -1)
+                s = np.maximum(s, (np.abs(out - base[idx]) / scale[idx]).max(1))
+        return s
+
+    S = sens(np.arange(len(A)), QUICK_SCALES, 2)
+    bad = np.nonzero(err > C_SENS * S + FLOOR)[0]
+    if len(bad):
+        S[bad] = np.maximum(S[bad], sens(bad, DEEP_SCALES, 48))
+    still = bad[err[bad] > C_SENS * S[bad] + FLOOR]
+    summary = '%s: %d matrices, err median %.2e max %.2e, %d needed the deep probe' % (what, len(A), np.median(err),
+                                                                                      err.max(), len(bad))
+    assert len(still) == 0, 'UNEXPLAINED: %s | %s' % ([(int(i), float(err[i]), float(S[i])) for i in still[:10]], summary)
+    return summary

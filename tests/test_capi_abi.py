@@ -77,3 +77,21 @@ def test_flop_model_is_consistent():
     import bench
     assert 45000 < bench.algorithmic_flops('iiwa') < 60000       # ~50 kFLOP / env-step
     assert bench.algorithmic_flops('circle') < bench.algorithmic_flops('planar') < bench.algorithmic_flops('iiwa')
+
+
+def test_observation_bounds_follow_the_reference(lib_built, golden):
+    """Drop-in detail: the MDPInfo of the iiwa env carries the finite bounds of env_single.py:69-80, with
+    the joint limits of the reference's URDF (golden set G10), so MinMaxPreprocessor normalises what it normalises there."""
+    import torch  # noqa: F401  (engine imports it)
+    from rl_on_manifold_amd import _lib
+    from rl_on_manifold_amd.engine import BatchedAtacomEnv
+    g = golden('iiwa_urdf')
+    lo, hi = BatchedAtacomEnv.observation_bounds(_lib.ENV_IIWA, _lib.default_config(_lib.ENV_IIWA))
+    assert np.allclose(lo[:3], [-1, -0.5, -np.pi]) and np.allclose(hi[:3], [1, 0.5, np.pi])
+    assert np.all(np.isinf(lo[3:6])) and np.all(np.isinf(hi[3:6]))
+    assert np.allclose(hi[6:12], g['pos_upper'][:6]) and np.allclose(lo[6:12], -g['pos_upper'][:6])
+    assert np.allclose(hi[12:18], g['vel_limit'][:6]) and np.allclose(lo[12:18], -g['vel_limit'][:6])
+    lo, hi = BatchedAtacomEnv.observation_bounds(_lib.ENV_PLANAR, _lib.default_config(_lib.ENV_PLANAR))
+    assert lo.shape == (12,) and np.isfinite(hi[[0, 1, 2, 6, 7, 8, 9, 10, 11]]).all()
+    lo, hi = BatchedAtacomEnv.observation_bounds(_lib.ENV_CIRCLE, _lib.default_config(_lib.ENV_CIRCLE))
+    assert np.all(np.isinf(lo)) and lo.shape == (4,)                                   # circle_base.py:21-22

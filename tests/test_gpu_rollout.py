@@ -29,7 +29,7 @@ def _policy(D, k, seed=0):
                      torch.randn(k, 64, generator=g) * 0.1, torch.zeros(k), std=torch.full((k,), 0.3))
 
 
-@pytest.mark.parametrize('lanes', [1, 2, 4])
+@pytest.mark.parametrize('lanes', [1, 2, 4, 8])
 @pytest.mark.parametrize('name', ['circle', 'planar', 'iiwa'])
 def test_packed_rollout_is_bitwise_the_array_rollout(name, lanes):
     """atacom_rollout_packed writes exactly what atacom_rollout writes, as one record per (step, env); a padded env
@@ -199,3 +199,35 @@ def test_bench_spawns_its_own_ranks():
     res = _run_bench(['--gpus', '2', '--batch', '2048'], env={'BENCH_DIST_BACKEND': 'gloo'})
     assert res['n_gpus'] == 2 and res['config']['global_batch'] == 4096
     assert res['collection']['records'] == [2, 120, 2048, 44] and res['collection']['allgather_ms'] > 0
+
+
+def test_vectorized_env_core_shaped_loop():
+    """The loop a vectorised Core runs (examples/circle_exp.py:26,42,72-73 in batch form): reset_all, step_all until every
+    environment delivered an episode (finished ones masked out and frozen), then get_constraints_logs."""
+    from rl_on_manifold_amd import VectorizedAtacomEnv
+    n = 300
+    env = VectorizedAtacomEnv('iiwa', n, horizon=9)
+    assert env.number == n and env.info.horizon == 9
+    lo, hi = env.info.observation_space.low, env.info.observation_space.high
+    assert np.isfinite(hi[6:]).all() and np.isinf(hi[3:6]).all()
+    active = torch.ones(n, dtype=torch.bool, device=DEV)
+    obs, _ = env.reset_all(active)
+    assert obs.shape == (n, 18)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    steps = torch.zeros(n, dtype=torch.long, device=DEV)
+    frozen = None
+    for t in range(12):
+        a = torch.rand((n, 5), device=DEV, generator=g) * 2 - 1
+        prev = obs.clone()
+        obs, r, ab, info = env.step_all(active, a)
+        steps += active
+        assert torch.equal(obs[~active], prev[~active])            # masked-out environments do not move
+        assert (r[~active] == 0).all() and not ab[~active].any()
+        active = active & ~info['last']
+        if not bool(active.any()):
+            break
+    assert (steps <= 9).all() and int((steps == 9).sum()) > 0 and not bool(active.any())
+    q = obs[:, 6:12].cpu().numpy()
+    assert (np.abs(q) <= hi[6:12] + 1e-6).all()                     # ATACOM keeps the joints inside the bounds it advertises
+    c_avg, c_max, c_dq = env.get_constraints_logs()
+    assert np.isfinite([c_avg, c_max, c_dq]).all() and c_max < 0.05
