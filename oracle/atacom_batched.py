@@ -284,6 +284,12 @@ class BatchedAtacomEnv:
         Jc[:, :, :nq] = sp.K[None, :, None] * J + 0.0     # '+ 0.0': -0.0 -> +0.0 like the reference's matmul
         idx = np.arange(ng)
         Jc[:, nf + idx, nq + idx] = s
+        noise = getattr(self, 'jc_noise', None)
+        if noise is not None:
+            # sensitivity probes only (tests/parity_tools.py): an UNSTRUCTURED perturbation of J_c -- every entry,
+            # structural zeros included -- of size eps * max|J_c|: what rounding inside a float32 factorisation amounts to
+            eps, rng = noise
+            Jc = Jc + eps * np.abs(Jc).max((1, 2), keepdims=True) * rng.choice([-1.0, 1.0], Jc.shape)
         psi = Jdq + sp.K * bst
         c = fun + sp.K * Jdq
         c[:, nf:] += 0.5 * s ** 2

@@ -2,9 +2,10 @@
 
 The reference algorithm is discontinuous (rref's 0.05 pivot tolerance, atacom.py:128; contact / rim / latch decisions of
 the puck model) and, away from its discontinuities, has a large and strongly state-dependent Lipschitz constant (the
-slack dynamics ~ 1/s; four chained sub-steps).  A float32 evaluation is a float64 evaluation of slightly perturbed data
-(backward stability), so the honest bound on |HIP_f32 - oracle_f64| is the oracle's own response to float32-sized
-perturbations of its inputs:
+slack dynamics ~ 1/s; four chained sub-steps; a LAPACK null basis that is ill-determined -- amplification up to 1e5 --
+whenever joints sit near zero).  A float32 evaluation is a float64 evaluation of slightly perturbed data (backward
+stability), so the honest bound on |HIP_f32 - oracle_f64| is the oracle's own response to float32-sized perturbations
+of its inputs AND of the matrix J_c it factorises (all entries, structural zeros included):
 
     sens(x) = max over perturbations d, |d_i| <= eps_rel * |x_i|, of | oracle(x + d) - oracle(x) |
 
@@ -48,6 +49,11 @@ def perturbed(o, scale, rng, fields=('q', 'dq', 's', 'puck')):
     for f in fields:
         arr = getattr(p, f)
         arr *= 1.0 + scale * rng.choice([-1.0, 1.0], arr.shape)
+    # and an unstructured perturbation of J_c itself (structural zeros included) at the same relative size: rounding inside
+    # a float32 factorisation is exactly that, and the reference's LAPACK null basis responds to it with an amplification
+    # of up to ~1e5 when joints sit near zero (nearly decoupled joint-limit rows: a near-breakdown of the Golub-Kahan
+    # recurrence) -- see DESIGN.md section 2 and profiles/r02_parity_sensitivity.md
+    p.jc_noise = (scale, rng)
     return p
 
 
@@ -62,7 +68,7 @@ class SensitivityRecorder:
         self.step_fn = step_fn
         self.rng = np.random.default_rng(seed)
         self.fields = state_fields
-        self.snaps, self.inputs, self.base, self.err, self.sens = [], [], [], [], []
+        self.snaps, self.inputs, self.base, self.err, self.sens, self.where = [], [], [], [], [], []
 
     def _sens(self, o, inputs, base, scales, draws):
         s = np.zeros(o.B)
@@ -87,11 +93,12 @@ class SensitivityRecorder:
 
     def compare(self, t, dev_out):
         base = self.base[t]
-        e = (np.abs(np.asarray(dev_out, dtype=np.float64) - base) / np.maximum(1.0, np.abs(base))).max(1)
-        if len(self.err) <= t:
-            self.err.append(e)
-        else:
-            self.err[t] = e
+        rel = np.abs(np.asarray(dev_out, dtype=np.float64) - base) / np.maximum(1.0, np.abs(base))
+        e = rel.max(1)
+        while len(self.err) <= t:
+            self.err.append(None)
+            self.where.append(None)
+        self.err[t], self.where[t] = e, rel.argmax(1)
         return e
 
     def record(self, o, inputs, dev_out):
@@ -103,7 +110,7 @@ class SensitivityRecorder:
     def fresh(self):
         """A recorder sharing the prepared oracle data, with an empty error log (one per device configuration)."""
         r = copy.copy(self)
-        r.err = []
+        r.err, r.where = [], []
         r.sens = [x.copy() for x in self.sens]
         return r
 
@@ -120,12 +127,12 @@ class SensitivityRecorder:
             for j, b in enumerate(idx):
                 S[t, b] = max(S[t, b], s2[j])
                 if E[t, b] > C_SENS * S[t, b] + FLOOR:
-                    unexplained.append((int(t), int(b), float(E[t, b]), float(S[t, b])))
+                    unexplained.append((int(t), int(b), float(E[t, b]), float(S[t, b]), 'output %d' % self.where[t][b]))
         ratio = E / (C_SENS * S + FLOOR)
         summary = ('%s: %d samples, err median %.2e / p99.9 %.2e / max %.2e; err / (C sens + floor) max %.2f; '
                    '%d samples needed the deep probe' % (what, E.size, np.median(E), np.quantile(E, 0.999), E.max(),
                                                          ratio.max(), n_deep))
-        assert not unexplained, 'UNEXPLAINED float32 errors (t, env, err, sens): %s | %s' % (unexplained[:10], summary)
+        assert not unexplained, 'UNEXPLAINED float32 errors (t, env, err, sens, where): %s | %s' % (unexplained[:10], summary)
         assert np.median(E) < 2e-5, summary            # and the bulk is at rounding level
         return summary
 
@@ -143,7 +150,10 @@ def assert_matrix_fn_explained(fn, A, dev_out, what='', seed=0):
         s = np.zeros(len(idx))
         for sc in scales:
             for _ in range(draws):
-                out = fn(A[idx] * (1.0 + sc * rng.choice([-1.0, 1.0], A[idx].shape))).reshape(len(idx), -1)
+                Ai = A[idx]
+                Ap = Ai * (1.0 + sc * rng.choice([-1.0, 1.0], Ai.shape)) \
+                    + sc * np.abs(Ai).max((1, 2), keepdims=True) * rng.choice([-1.0, 1.0], Ai.shape)
+                out = fn(Ap).reshape(len(idx), -1)
                 s = np.maximum(s, (np.abs(out - base[idx]) / scale[idx]).max(1))
         return s
 
