@@ -82,6 +82,13 @@ typedef struct atacom_config {
                                      reference's reset on the device: circle point + tangential velocity
                                      (circle_base.py:36-42), puck position in hit_range (env_hitting.py:24-25) */
     int32_t seed;                 /* seed of the counter-based generator hash(seed, env, episode, draw) */
+    int32_t dynamics_mode;        /* 0 = kinematic: inverse dynamics o forward dynamics taken as the identity, q'' integrates
+                                     directly (default).  1 = rigid body (ATACOM_ENV_IIWA only, row N4):
+                                     per sub-step the torque is the inverse dynamics of the nine-joint chain
+                                     (iiwa_hit_atacom.py:58-63), saturated at the URDF effort limits, and the controlled
+                                     joints follow the forward dynamics under it with the URDF joint damping, joint 7 and
+                                     the striker's universal joint riding position servos (env_single.py:137-185) */
+    int32_t reserved0;
 } atacom_config;
 
 typedef struct atacom_handle atacom_handle;
@@ -172,6 +179,24 @@ int atacom_get_stats(atacom_handle* h, double out[3], int32_t clear, void* strea
 /* Parity injection / checkpointing: d_state [batch, state_dim]. */
 int atacom_get_state(atacom_handle* h, void* d_state, void* stream);
 int atacom_set_state(atacom_handle* h, const void* d_state, void* stream);
+
+/* Row N4: the three servo joints of the rigid-body mode (joint 7, striker_joint_1, striker_joint_2):
+ * d_aux [batch, 6] = [q7, qu1, qu2, dq7, dqu1, dqu2].  ATACOM_ENV_IIWA handles only. */
+int atacom_get_aux_state(atacom_handle* h, void* d_aux, void* stream);
+int atacom_set_aux_state(atacom_handle* h, const void* d_aux, void* stream);
+
+/* Row N4 primitives on n states of the nine movable joints of urdf/iiwa_1.urdf (q, dq, ddq: [n, 9] = joint_1..7,
+ * striker_joint_1, striker_joint_2):
+ *   atacom_inverse_dynamics: d_tau [n, 9] = M(q) ddq + C(q, dq) dq + g(q)   -- PyBullet calculateInverseDynamics as the
+ *     reference calls it (iiwa_hit_atacom.py:58-63; gravity (0, 0, -9.81), no joint damping); d_M [n, 9, 9] (may be
+ *     NULL) receives the joint-space inertia matrix;
+ *   atacom_forward_dynamics: d_ddq6 [n, 6] = accelerations of the six controlled joints under the torques d_tau6
+ *     [n, 6], the servo joints following the prescribed accelerations d_ddq_aux [n, 3] (NULL = 0), with
+ *     (use_damping != 0) or without the URDF joint damping. */
+int atacom_inverse_dynamics(int32_t dtype, int32_t n, const void* d_q, const void* d_dq, const void* d_ddq, void* d_tau,
+                            void* d_M, void* stream);
+int atacom_forward_dynamics(int32_t dtype, int32_t n, const void* d_q, const void* d_dq, const void* d_tau6,
+                            const void* d_ddq_aux, int32_t use_damping, void* d_ddq6, void* stream);
 
 /* Stand-alone batched primitives (no handle), for parity tests of individual reference functions.
  *   atacom_nullspace: for n matrices Jc [n, c, c+k] (row-major) and right-hand sides [n, c]:

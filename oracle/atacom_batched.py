@@ -222,6 +222,9 @@ class BatchedAtacomEnv:
         self.dq = np.zeros((batch, nq))
         self.s = np.zeros((batch, spec.n_g))
         self.puck = np.zeros((batch, 6))
+        # row N4 (dynamics_mode = 1): the three servo joints -- joint 7 and the striker's universal joint
+        self.qx = np.zeros((batch, 3))
+        self.dqx = np.zeros((batch, 3))
         self.has_hit = np.zeros(batch, dtype=bool)
         self.r_hit = np.zeros(batch)
         self.vel_hit_x = np.zeros(batch)
@@ -242,6 +245,7 @@ class BatchedAtacomEnv:
         m = np.ones(self.B, dtype=bool) if mask is None else np.asarray(mask, dtype=bool)
         self.q[m], self.dq[m], self.puck[m] = self.init_q[m], self.init_dq[m], self.init_puck[m]
         self.has_hit[m], self.r_hit[m], self.vel_hit_x[m], self.t[m] = False, 0.0, 0.0, 0
+        self.qx[m], self.dqx[m] = 0.0, 0.0
         if self.random_init and m.any():
             env, ep = np.arange(self.B)[m], self.episode[m]
             u = [device_uniform(self.seed, env, ep, i) for i in range(4)]
@@ -368,6 +372,8 @@ class BatchedAtacomEnv:
                 mu = self.tangent_space_accel(q_ctl, dq_ctl, self.s, alpha, terms)
                 self.s = self.s + mu[:, nq:] * sp.dt
                 ddq = self.acc_truncation(dq_ctl, mu[:, :nq])
+                if sp.dynamics_mode == 1:
+                    ddq = self._rigid_body_substep(q_sim, dq_sim, ddq)
                 dq_sim = np.clip(dq_sim + ddq * sp.dt, -1.5 * sp.vel_max, 1.5 * sp.vel_max)
                 q_sim = q_sim + dq_sim * sp.dt
             self.q, self.dq = q_sim, dq_sim
@@ -383,6 +389,33 @@ class BatchedAtacomEnv:
             self._log(cm, cm, (np.abs(self.dq) - sp.vel_max).max(-1))
         self.t += 1
         return self.observation(), reward, absorbing, {}
+
+    SERVO_GAIN = 0.1          # PyBullet's default positionGain of POSITION_CONTROL (env_base.py:64-70)
+
+    def _rigid_body_substep(self, q_sim, dq_sim, ddq_des):
+        """Row N4, dynamics_mode = 1 (the model of this build where Bullet was), per sub-step:
+          tau  = inverse dynamics of the nine-joint chain for [ddq_des, 0, 0, 0]   (acc_to_ctrl_action,
+                 iiwa_hit_atacom.py:58-63)
+          servo joints (joint 7, universal joint; POSITION_CONTROL, env_base.py:64-70): velocity set-point
+                 v* = clip(gain (target - q) / dt, 1.5 v_max), targets from env_single.py:137-185; ddq_b = (v* - dq_b) / dt
+          ddq_a = forward dynamics of the six controlled joints under tau, URDF joint damping and the servo joints'
+                 prescribed accelerations.
+        Advances the servo joints; returns ddq_a (the caller integrates the controlled joints)."""
+        from . import dynamics as D
+        sp = self.spec
+        B = q_sim.shape[0]
+        q9 = np.concatenate([q_sim, self.qx], 1)
+        dq9 = np.concatenate([dq_sim, self.dqx], 1)
+        tau = D.rnea(q9, dq9, np.concatenate([ddq_des, np.zeros((B, 3))], 1))[:, :6]
+        tgt = np.concatenate([D.joint7_target(q_sim, self.qx[:, 0])[:, None],
+                              D.universal_joint_target(q9[:, :7])], 1)
+        vmax = 1.5 * np.array([robots.IIWA_VEL_LIMIT[6], 3.1415926, 3.1415926])     # iiwa_1.urdf:297,384,397
+        vstar = np.clip(self.SERVO_GAIN * (tgt - self.qx) / sp.dt, -vmax, vmax)
+        ddq_b = (vstar - self.dqx) / sp.dt
+        ddq_a = D.forward_dynamics(q9, dq9, tau, ddq_b)
+        self.dqx = vstar
+        self.qx = self.qx + vstar * sp.dt
+        return ddq_a
 
     def _puck_substep(self, mallet, mallet_vel):
         """Batched version of atacom_scalar.ScalarAtacomEnv._puck_substep (contact model of this build, row N1)."""

@@ -55,6 +55,8 @@ class EnvSpec:
     mode: int = 0            # MODE_*
     term_tol: float = 0.1    # circle_terminated.py:13
     base_xy: np.ndarray = field(default_factory=lambda: np.zeros(2))
+    dynamics_mode: int = 0   # 0: inverse o forward dynamics = identity; 1: rigid body (row N4, iiwa,
+                             # oracle/dynamics.py -- implemented by the batched oracle only)
 
     @property
     def n_c(self):
@@ -105,14 +107,14 @@ def planar_spec(horizon=120, gamma=0.99, Kc=240.0, dt=1 / 240.0, substeps=4, bia
                    base_xy=robots.PLANAR_BASE_XYZ[:2].copy())
 
 
-def iiwa_spec(horizon=120, gamma=0.99, Kc=240.0, dt=1 / 240.0, substeps=4, bias_mode='reference'):
+def iiwa_spec(horizon=120, gamma=0.99, Kc=240.0, dt=1 / 240.0, substeps=4, bias_mode='reference', dynamics_mode=0):
     """iiwa_hit_atacom.py:23-40 (Kq = 4 acc_max / vel_max)."""
     acc = np.full(6, 10.0)
     vel = robots.IIWA_VEL_LIMIT[:6].copy()
     return EnvSpec(ENV_IIWA, 6, 1, 11, K=np.array([0.1] + [0.5] * 5 + [1.0] * 6),
                    Kc=np.full(12, float(Kc)), vel_max=vel, acc_max=acc, Kq=4 * acc / vel, dt=dt,
                    substeps=substeps, horizon=horizon, gamma=gamma, obs_dim=18, bias_mode=bias_mode,
-                   base_xy=robots.IIWA_BASE_XYZ[:2].copy())
+                   base_xy=robots.IIWA_BASE_XYZ[:2].copy(), dynamics_mode=dynamics_mode)
 
 
 def make_spec(env_id, **kw):

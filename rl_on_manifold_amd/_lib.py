@@ -14,7 +14,8 @@ ENV_CIRCLE, ENV_PLANAR, ENV_IIWA, ENV_CIRCLE_EC, ENV_CIRCLE_T = 0, 1, 2, 3, 4
 F32, F64 = 0, 1
 MAX_C, MAX_Q = 12, 6
 
-EXPORTS = ['atacom_rollout_mlp', 'atacom_rollout_packed', 'atacom_default_config', 'atacom_get_dims', 'atacom_create', 'atacom_destroy', 'atacom_reset',
+EXPORTS = ['atacom_rollout_mlp', 'atacom_rollout_packed', 'atacom_get_aux_state', 'atacom_set_aux_state',
+           'atacom_inverse_dynamics', 'atacom_forward_dynamics', 'atacom_default_config', 'atacom_get_dims', 'atacom_create', 'atacom_destroy', 'atacom_reset',
            'atacom_step', 'atacom_rollout', 'atacom_get_stats', 'atacom_get_state', 'atacom_set_state',
            'atacom_nullspace', 'atacom_constraint_terms', 'atacom_last_error', 'atacom_version']
 
@@ -27,7 +28,8 @@ class AtacomConfig(C.Structure):
                 ('dt', C.c_double), ('rref_tol', C.c_double), ('action_penalty', C.c_double), ('gamma', C.c_double),
                 ('K', C.c_double * MAX_C), ('Kc', C.c_double * MAX_C), ('vel_max', C.c_double * MAX_Q),
                 ('acc_max', C.c_double * MAX_Q), ('Kq', C.c_double * MAX_Q), ('pos_limit', C.c_double * MAX_Q),
-                ('base_xy', C.c_double * 2), ('link', C.c_double * 3), ('term_tol', C.c_double), ('random_init', C.c_int32), ('seed', C.c_int32)]
+                ('base_xy', C.c_double * 2), ('link', C.c_double * 3), ('term_tol', C.c_double), ('random_init', C.c_int32), ('seed', C.c_int32),
+                ('dynamics_mode', C.c_int32), ('reserved0', C.c_int32)]
 
 
 class AtacomMlp(C.Structure):
@@ -84,6 +86,10 @@ def load():
     lib.atacom_get_stats.argtypes = [vp, C.POINTER(C.c_double * 3), i32, vp]
     lib.atacom_get_state.argtypes = [vp, vp, vp]
     lib.atacom_set_state.argtypes = [vp, vp, vp]
+    lib.atacom_get_aux_state.argtypes = [vp, vp, vp]
+    lib.atacom_set_aux_state.argtypes = [vp, vp, vp]
+    lib.atacom_inverse_dynamics.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.atacom_forward_dynamics.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.atacom_nullspace.argtypes = [i32, i32, i32, i32, vp, vp, C.c_double, vp, vp, vp, vp]
     lib.atacom_constraint_terms.argtypes = [C.POINTER(AtacomConfig), i32, vp, vp, vp, vp, vp, vp]
     lib.atacom_last_error.restype = C.c_char_p

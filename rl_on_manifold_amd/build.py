@@ -17,7 +17,8 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + \
     os.environ.get('ATACOM_HIPCC_FLAGS', '').split()
-UNITS = ['atacom_circle.hip', 'atacom_planar.hip', 'atacom_iiwa.hip', 'atacom_iiwa_f64.hip', 'atacom_capi.cpp']
+UNITS = ['atacom_circle.hip', 'atacom_planar.hip', 'atacom_iiwa.hip', 'atacom_iiwa_f64.hip', 'atacom_iiwa_dyn.hip',
+         'atacom_capi.cpp']
 # per-unit extra flags (none at present: -amdgpu-sched-strategy=max-ilp was tried per unit -- planar step kernel -4 %,
 # planar policy-rollout kernel +19 %, iiwa quad kernel +8 % -- and dropped, profiles/r01_lanes_vs_batch.md)
 UNIT_FLAGS = {}

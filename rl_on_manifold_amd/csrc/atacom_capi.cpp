@@ -149,6 +149,7 @@ int atacom_default_config(int32_t env_id, atacom_config* c) {
     c->gamma = 0.99;
     c->action_penalty = 1e-3;    // env_hitting.py:10
     c->term_tol = 0.1;           // circle_terminated.py:13
+    c->dynamics_mode = 0;
     if (env_id == ATACOM_ENV_CIRCLE || env_id == ATACOM_ENV_CIRCLE_EC || env_id == ATACOM_ENV_CIRCLE_T) {
         // circle_atacom.py:7-18 == circle_error_correction.py:8-21 (same constraints and gains)
         c->substeps = 1; c->horizon = 500; c->dt = 0.01; c->hold_q = 0;
@@ -198,6 +199,8 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
     if (cfg->lanes_per_env != 0 && cfg->lanes_per_env != 1 && cfg->lanes_per_env != 2 && cfg->lanes_per_env != 4 &&
         cfg->lanes_per_env != 8)
         return fail(ATACOM_E_INVALID, "atacom_create: lanes_per_env must be 0 (auto), 1, 2, 4 or 8");
+    if (cfg->dynamics_mode != 0 && !(cfg->dynamics_mode == 1 && cfg->env_id == ATACOM_ENV_IIWA))
+        return fail(ATACOM_E_INVALID, "atacom_create: dynamics_mode 1 (rigid body) exists for ATACOM_ENV_IIWA only");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(ATACOM_E_INVALID, "atacom_create: no such device");
@@ -271,6 +274,10 @@ int atacom_step(atacom_handle* h, const void* d_action, void* d_obs, void* d_rew
     if (!d_action || !d_obs || !d_reward || !d_absorbing)
         return fail(ATACOM_E_INVALID, "atacom_step: d_action, d_obs, d_reward and d_absorbing are required");
     ON_DEVICE(h);
+    if (h->cfg.dynamics_mode == 1)
+        atacom::ops_iiwa_dyn(h->cfg.dtype)->step(h->cfg, pick_lanes(h->cfg), h->f, h->ip, d_action, d_obs, d_reward,
+                                                  d_absorbing, d_last, (hipStream_t)stream);
+    else
     h->ops->step(h->cfg, pick_lanes(h->cfg), h->f, h->ip, d_action, d_obs, d_reward, d_absorbing, d_last, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
@@ -283,8 +290,9 @@ int atacom_rollout(atacom_handle* h, int32_t n_steps, const void* d_actions, voi
     if (!d_actions || !d_obs || !d_reward || !d_absorbing || !d_last)
         return fail(ATACOM_E_INVALID, "atacom_rollout: all buffers except d_next_obs are required");
     ON_DEVICE(h);
-    h->ops->rollout(h->cfg, pick_lanes(h->cfg), n_steps, h->f, h->ip, d_actions, d_obs, d_next_obs, d_reward, d_absorbing, d_last,
-                    nullptr, 0, (hipStream_t)stream);
+    (h->cfg.dynamics_mode == 1 ? atacom::ops_iiwa_dyn(h->cfg.dtype)->rollout : h->ops->rollout)(
+        h->cfg, pick_lanes(h->cfg), n_steps, h->f, h->ip, d_actions, d_obs, d_next_obs, d_reward, d_absorbing, d_last,
+        nullptr, 0, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
 }
@@ -298,6 +306,8 @@ int atacom_rollout_mlp(atacom_handle* h, int32_t n_steps, const atacom_mlp* net,
     if (vrc != ATACOM_OK) return vrc;
     if (!d_obs || !d_actions || !d_reward || !d_absorbing || !d_last)
         return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: all output buffers except d_next_obs are required");
+    if (h->cfg.dynamics_mode == 1)
+        return fail(ATACOM_E_UNSUPPORTED, "the policy rollout kernels have no rigid-body form (dynamics_mode 1)");
     ON_DEVICE(h);
     const int rc = h->ops->rollout_mlp(h->cfg, pick_lanes(h->cfg), n_steps, *net, h->f, h->ip, d_noise, d_obs,
                                        d_next_obs, d_actions, d_reward, d_absorbing, d_last, nullptr, 0,
@@ -318,9 +328,12 @@ int atacom_rollout_packed(atacom_handle* h, int32_t n_steps, const void* d_actio
     if (record_batch_stride < h->cfg.batch)
         return fail(ATACOM_E_INVALID, "atacom_rollout_packed: record_batch_stride must be >= batch");
     ON_DEVICE(h);
+    if (!d_actions && h->cfg.dynamics_mode == 1)
+        return fail(ATACOM_E_UNSUPPORTED, "the policy rollout kernels have no rigid-body form (dynamics_mode 1)");
     if (d_actions) {
-        h->ops->rollout(h->cfg, pick_lanes(h->cfg), n_steps, h->f, h->ip, d_actions, nullptr, nullptr, nullptr, nullptr,
-                        nullptr, d_records, record_batch_stride, (hipStream_t)stream);
+        (h->cfg.dynamics_mode == 1 ? atacom::ops_iiwa_dyn(h->cfg.dtype)->rollout : h->ops->rollout)(
+            h->cfg, pick_lanes(h->cfg), n_steps, h->f, h->ip, d_actions, nullptr, nullptr, nullptr, nullptr, nullptr,
+            d_records, record_batch_stride, (hipStream_t)stream);
     } else {
         const int vrc = check_mlp(h, net, "atacom_rollout_packed");
         if (vrc != ATACOM_OK) return vrc;
@@ -369,6 +382,42 @@ int atacom_set_state(atacom_handle* h, const void* d_state, void* stream) {
     if (!h || !d_state) return fail(ATACOM_E_INVALID, "atacom_set_state: null argument");
     ON_DEVICE(h);
     h->ops->set_state(h->cfg, h->f, h->ip, d_state, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+
+int atacom_get_aux_state(atacom_handle* h, void* d_aux, void* stream) {
+    if (!h || !d_aux) return fail(ATACOM_E_INVALID, "atacom_get_aux_state: null argument");
+    if (h->cfg.env_id != ATACOM_ENV_IIWA) return fail(ATACOM_E_INVALID, "atacom_get_aux_state: ATACOM_ENV_IIWA only");
+    ON_DEVICE(h);
+    atacom::ops_iiwa_dyn(h->cfg.dtype)->get_aux(h->cfg, h->f, d_aux, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+
+int atacom_set_aux_state(atacom_handle* h, const void* d_aux, void* stream) {
+    if (!h || !d_aux) return fail(ATACOM_E_INVALID, "atacom_set_aux_state: null argument");
+    if (h->cfg.env_id != ATACOM_ENV_IIWA) return fail(ATACOM_E_INVALID, "atacom_set_aux_state: ATACOM_ENV_IIWA only");
+    ON_DEVICE(h);
+    atacom::ops_iiwa_dyn(h->cfg.dtype)->set_aux(h->cfg, h->f, d_aux, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+
+int atacom_inverse_dynamics(int32_t dtype, int32_t n, const void* d_q, const void* d_dq, const void* d_ddq, void* d_tau,
+                            void* d_M, void* stream) {
+    if (dtype != ATACOM_F32 && dtype != ATACOM_F64) return fail(ATACOM_E_INVALID, "atacom_inverse_dynamics: bad dtype");
+    if (n <= 0 || !d_q || !d_dq || !d_ddq || !d_tau) return fail(ATACOM_E_INVALID, "atacom_inverse_dynamics: null buffer");
+    atacom::ops_iiwa_dyn(dtype)->inverse_dynamics(n, d_q, d_dq, d_ddq, d_tau, d_M, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+
+int atacom_forward_dynamics(int32_t dtype, int32_t n, const void* d_q, const void* d_dq, const void* d_tau6,
+                            const void* d_ddq_aux, int32_t use_damping, void* d_ddq6, void* stream) {
+    if (dtype != ATACOM_F32 && dtype != ATACOM_F64) return fail(ATACOM_E_INVALID, "atacom_forward_dynamics: bad dtype");
+    if (n <= 0 || !d_q || !d_dq || !d_tau6 || !d_ddq6) return fail(ATACOM_E_INVALID, "atacom_forward_dynamics: null buffer");
+    atacom::ops_iiwa_dyn(dtype)->forward_dynamics(n, d_q, d_dq, d_tau6, d_ddq_aux, use_damping, d_ddq6, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
 }

@@ -39,7 +39,7 @@ struct Iiwa {
 // Everything a kernel needs besides per-env state; passed by value (kernarg segment -> SGPRs).
 template <typename T>
 struct Params {
-    int batch, substeps, horizon, hold_q, bias_mode, auto_reset, random_init;
+    int batch, substeps, horizon, hold_q, bias_mode, auto_reset, random_init, dynamics_mode;
     unsigned int seed;
     T dt, rref_tol, action_penalty, alpha_max;
     T K[12], Kc[12], vel_max[6], acc_max[6], Kq[6], pos_limit[6];

@@ -13,6 +13,7 @@
 #include "atacom_envs.h"
 #include "atacom_quad.h"
 #include "atacom_policy.h"
+#include "atacom_dynamics.h"
 
 namespace atacom {
 
@@ -26,7 +27,9 @@ template <typename E>
 struct Planes {
     static constexpr int Q = 0, DQ = Q + E::NQ, S = DQ + E::NQ, PUCK = S + E::NG, RHIT = PUCK + 6,
                          VHX = RHIT + 1, IQ = VHX + 1, IDQ = IQ + E::NQ, IS = IDQ + E::NQ, IPUCK = IS + E::NG,
-                         SSUM = IPUCK + 6, SCMAX = SSUM + 1, SDQMAX = SCMAX + 1, COUNT = SDQMAX + 1;
+                         SSUM = IPUCK + 6, SCMAX = SSUM + 1, SDQMAX = SCMAX + 1,
+                         // row N4 (iiwa): the three servo joints of the rigid-body mode, positions then velocities
+                         QX = SDQMAX + 1, DQX = QX + 3, COUNT = (E::ID == 2) ? DQX + 3 : SDQMAX + 1;
     static constexpr int I_HIT = 0, I_T = 1, I_CNT = 2, I_EP = 3, ICOUNT = 4;   // I_EP: episodes started (RNG counter)
     static constexpr int STATE_DIM = 2 * E::NQ + E::NG + 6 + 4;
     static constexpr int INIT_DIM = 2 * E::NQ + (E::PUCK ? 6 : 0);
@@ -45,7 +48,22 @@ struct EnvState {
     T q[E::NQ], dq[E::NQ], s[E::NG], puck[6];
     T r_hit, vel_hit_x;
     int has_hit, t;
+    T qx[3], dqx[3];            // servo joints (rigid-body mode only; untouched otherwise)
 };
+
+// the servo-joint planes are loaded / stored only by the rigid-body kernels (DYN)
+template <typename T, typename E>
+__device__ __forceinline__ void load_aux(const T* __restrict__ f, int B, int b, EnvState<T, E>& st) {
+    using L = Planes<E>;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { st.qx[i] = f[(L::QX + i) * (size_t)B + b]; st.dqx[i] = f[(L::DQX + i) * (size_t)B + b]; }
+}
+template <typename T, typename E>
+__device__ __forceinline__ void store_aux(T* __restrict__ f, int B, int b, const EnvState<T, E>& st) {
+    using L = Planes<E>;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { f[(L::QX + i) * (size_t)B + b] = st.qx[i]; f[(L::DQX + i) * (size_t)B + b] = st.dqx[i]; }
+}
 
 template <typename T>
 struct StepOut {
@@ -107,6 +125,8 @@ __device__ __forceinline__ void load_init(const T* __restrict__ f, int B, int b,
     st.r_hit = st.vel_hit_x = T(0);
     st.has_hit = 0;
     st.t = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st.qx[i] = st.dqx[i] = T(0);      // the servo set-points vanish at the reset pose
 }
 
 template <typename T, typename E>
@@ -179,11 +199,59 @@ __device__ __forceinline__ void reset_env(const Params<T>& P, const T* __restric
     }
 }
 
+// ------------------------------------------------------------------ row N4: one physics sub-step of the rigid-body mode
+// ddq (in: the truncated acceleration ATACOM asks for; out: what the arm does) -- DESIGN.md section 4a:
+//   tau   = inverse dynamics of the nine-joint chain for [ddq, 0, 0, 0] at the SIMULATED state (acc_to_ctrl_action,
+//           iiwa_hit_atacom.py:58-63), saturated at the URDF effort limits (iiwa_1.urdf:74,112,149,186,223,260);
+//   servo joints (POSITION_CONTROL, env_base.py:64-70): velocity set-point v* = clip(0.1 (target - q) / dt, 1.5 v_max),
+//           targets env_single.py:137-185; their acceleration over the sub-step is prescribed, (v* - dq) / dt;
+//   ddq   = M_aa^-1 (tau - rnea_a(q, dq, [0; ddq_servo]) - D_a dq_a)       (hybrid forward dynamics, URDF joint damping).
+template <typename T, typename E>
+__device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<T, E>& st, T (&ddq)[E::NQ]) {
+    static_assert(E::NQ == 6, "iiwa only");
+    T q9[9], dq9[9];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { q9[i] = st.q[i]; dq9[i] = st.dq[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { q9[6 + i] = st.qx[i]; dq9[6 + i] = st.dqx[i]; }
+    Chain9<T> ch;
+    iiwa_chain9(q9, ch);
+    T dd[9], tau[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dd[i] = (i < 6) ? ddq[i < 6 ? i : 0] : T(0);
+    rnea9(ch, dq9, dd, tau);
+    constexpr T effort[6] = {T(320), T(320), T(176), T(176), T(110), T(40)};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) tau[i] = num<T>::min(num<T>::max(tau[i], -effort[i]), effort[i]);
+    const T q6[6] = {st.q[0], st.q[1], st.q[2], st.q[3], st.q[4], st.q[5]};
+    const T tgt[3] = {joint7_target(q6, st.qx[0]), universal_target(ch.a[6], ch.a[7]), T(0)};
+    constexpr T vmax[3] = {T(1.5 * 2.356194490192345), T(1.5 * 3.1415926), T(1.5 * 3.1415926)};     // urdf:297,384,397
+    T vstar[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        vstar[i] = num<T>::min(num<T>::max(T(0.1) * (tgt[i] - st.qx[i]) / P.dt, -vmax[i]), vmax[i]);
+        dd[6 + i] = (vstar[i] - st.dqx[i]) / P.dt;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dd[i] = T(0);
+    T bias[9];
+    rnea9(ch, dq9, dd, bias);
+    T rhs[6], Ml[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rhs[i] = tau[i] - bias[i] - (T)iiwa_body::DAMPING[i] * st.dq[i];
+    crba<T, 6>(ch, Ml);
+    chol_solve<T, 6>(Ml, rhs);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ddq[i] = rhs[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { st.dqx[i] = vstar[i]; st.qx[i] = num<T>::fma(vstar[i], P.dt, st.qx[i]); }
+}
+
 // ------------------------------------------------------------------ one env step (A1, A2, A13-A15)
 // LANES = 1: one environment per lane (atacom_linalg.h).  LANES = 4: one environment per DPP quad -- the
 // null-space solve is column-split over the quad (atacom_quad.h), everything else is computed redundantly
 // (and bitwise identically) by the four lanes; `lq` is the lane's index in its quad.
-template <typename T, typename E, int LANES, bool HOLD>
+template <typename T, typename E, int LANES, bool HOLD, bool DYN = false>
 __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st, const T (&act)[E::NK],
                                          StepOut<T>& out, const int lq) {
     constexpr int NQ = E::NQ, NF = E::NF, NG = E::NG, NC = E::NC, NN = E::NN, NK = E::NK;
@@ -367,8 +435,9 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 st.dq[i] = num<T>::fma(acc, P.dt, st.dq[i]);
             }
         } else {
-            // dynamics model of this build: ID o FD = identity, semi-implicit Euler,
-            // velocity clamp at 1.5 x limit (iiwa_hit_atacom.py:48-50)
+            if constexpr (DYN && E::ID == 2) rigid_body_substep<T, E>(P, st, ddq);      // row N4: ddq <- forward dynamics
+            // dynamics model of this build: ID o FD = identity (or the rigid-body mode above), semi-implicit
+            // Euler, velocity clamp at 1.5 x limit (iiwa_hit_atacom.py:48-50)
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const T vlim = T(1.5) * P.vel_max[i];
@@ -470,7 +539,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
 }
 
 // ------------------------------------------------------------------ kernels
-template <typename T, typename E, int LANES, bool HOLD>
+template <typename T, typename E, int LANES, bool HOLD, bool DYN = false>
 __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __restrict__ f, int* __restrict__ ip,
                                                const T* __restrict__ action, T* __restrict__ obs,
                                                T* __restrict__ reward, uint8_t* __restrict__ absorbing,
@@ -491,8 +560,9 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     T act[E::NK];
 #pragma unroll
     for (int k = 0; k < E::NK; ++k) act[k] = action[(size_t)b * E::NK + k];
+    if constexpr (DYN) load_aux<T, E>(f, B, b, st);
     StepOut<T> out;
-    env_step<T, E, LANES, HOLD>(P, st, act, out, lq);
+    env_step<T, E, LANES, HOLD, DYN>(P, st, act, out, lq);
     ATACOM_MARK("STORE");
     if (lq != 0) return;                       // the four lanes hold identical results; lane 0 writes
     write_obs<T, E>(P, st, obs + (size_t)b * E::OBS);
@@ -505,9 +575,10 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     ip[L::I_CNT * (size_t)B + b] = cnt0 + 1;
     if (P.auto_reset && out.last) reset_env<T, E>(P, f, ip, B, b, st);
     store_state<T, E>(f, ip, B, b, st);
+    if constexpr (DYN) store_aux<T, E>(f, B, b, st);
 }
 
-template <typename T, typename E, int LANES, bool HOLD>
+template <typename T, typename E, int LANES, bool HOLD, bool DYN = false>
 __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int n_steps, T* __restrict__ f,
                                                   int* __restrict__ ip, const T* __restrict__ actions,
                                                   T* __restrict__ obs, T* __restrict__ next_obs,
@@ -522,6 +593,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
     if (b >= B) return;
     EnvState<T, E> st;
     load_state<T, E>(f, ip, B, b, st);
+    if constexpr (DYN) load_aux<T, E>(f, B, b, st);
     T ssum = T(0), scmax = f[L::SCMAX * (size_t)B + b], sdq = f[L::SDQMAX * (size_t)B + b];
 #pragma unroll 1
     for (int t = 0; t < n_steps; ++t) {
@@ -540,7 +612,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
             }
         }
         StepOut<T> out;
-        env_step<T, E, LANES, HOLD>(P, st, act, out, lq);
+        env_step<T, E, LANES, HOLD, DYN>(P, st, act, out, lq);
         if (lq == 0) {
             if (rec) {
                 write_obs<T, E>(P, st, rrow + R::NOBS);
@@ -565,6 +637,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
     f[L::SDQMAX * (size_t)B + b] = sdq;
     ip[L::I_CNT * (size_t)B + b] += n_steps;
     store_state<T, E>(f, ip, B, b, st);
+    if constexpr (DYN) store_aux<T, E>(f, B, b, st);
 }
 
 // Row N2: rollout with the policy MLP evaluated in the kernel (atacom_policy.h).  d_actions_out receives the action
@@ -715,6 +788,7 @@ __global__ void __launch_bounds__(WAVE) k_reset(const Params<T> P, T* __restrict
         for (int g = 0; g < E::NG; ++g) f[(L::IS + g) * (size_t)B + b] = st.s[g];
         if (P.random_init && !init) reset_env<T, E>(P, f, ip, B, b, st);     // an explicit state wins over the draw
         store_state<T, E>(f, ip, B, b, st);
+        if constexpr (E::ID == 2) store_aux<T, E>(f, B, b, st);              // servo joints back to rest
     } else {
         load_state<T, E>(f, ip, B, b, st);
     }
@@ -819,6 +893,73 @@ __global__ void k_set_state(int B, T* __restrict__ f, int* __restrict__ ip, cons
     for (int i = 0; i < 6; ++i) st.puck[i] = o[k++];
     st.has_hit = (o[k++] != T(0)) ? 1 : 0; st.r_hit = o[k++]; st.vel_hit_x = o[k++]; st.t = (int)o[k++];
     store_state<T, E>(f, ip, B, b, st);
+}
+
+// servo-joint state <-> [B, 6] = [q7, qu1, qu2, dq7, dqu1, dqu2]  (iiwa)
+template <typename T, typename E>
+__global__ void k_get_aux(int B, const T* __restrict__ f, T* __restrict__ out) {
+    using L = Planes<E>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) out[(size_t)b * 6 + i] = f[(L::QX + i) * (size_t)B + b];
+}
+template <typename T, typename E>
+__global__ void k_set_aux(int B, T* __restrict__ f, const T* __restrict__ in) {
+    using L = Planes<E>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) f[(L::QX + i) * (size_t)B + b] = in[(size_t)b * 6 + i];
+}
+
+// row N4 primitives (atacom_inverse_dynamics / atacom_forward_dynamics)
+template <typename T>
+__global__ void __launch_bounds__(WAVE) k_inverse_dynamics(int n, const T* __restrict__ q, const T* __restrict__ dq,
+                                                           const T* __restrict__ ddq, T* __restrict__ tau,
+                                                           T* __restrict__ M) {
+    const int b = blockIdx.x * WAVE + threadIdx.x;
+    if (b >= n) return;
+    T q9[9], dq9[9], dd9[9], t9[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { q9[i] = q[(size_t)b * 9 + i]; dq9[i] = dq[(size_t)b * 9 + i]; dd9[i] = ddq[(size_t)b * 9 + i]; }
+    Chain9<T> ch;
+    iiwa_chain9(q9, ch);
+    rnea9(ch, dq9, dd9, t9);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) tau[(size_t)b * 9 + i] = t9[i];
+    if (M) {
+        T Ml[9][9];
+        crba<T, 9>(ch, Ml);
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) M[((size_t)b * 9 + i) * 9 + j] = M[((size_t)b * 9 + j) * 9 + i] = Ml[i][j];
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(WAVE) k_forward_dynamics(int n, const T* __restrict__ q, const T* __restrict__ dq,
+                                                           const T* __restrict__ tau6, const T* __restrict__ ddq_aux,
+                                                           int use_damping, T* __restrict__ ddq6) {
+    const int b = blockIdx.x * WAVE + threadIdx.x;
+    if (b >= n) return;
+    T q9[9], dq9[9], dd9[9], bias[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        q9[i] = q[(size_t)b * 9 + i]; dq9[i] = dq[(size_t)b * 9 + i];
+        dd9[i] = (i >= 6 && ddq_aux) ? ddq_aux[(size_t)b * 3 + (i >= 6 ? i - 6 : 0)] : T(0);
+    }
+    Chain9<T> ch;
+    iiwa_chain9(q9, ch);
+    rnea9(ch, dq9, dd9, bias);
+    T rhs[6], Ml[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        rhs[i] = tau6[(size_t)b * 6 + i] - bias[i] - (use_damping ? (T)iiwa_body::DAMPING[i] * dq9[i] : T(0));
+    crba<T, 6>(ch, Ml);
+    chol_solve<T, 6>(Ml, rhs);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ddq6[(size_t)b * 6 + i] = rhs[i];
 }
 
 // ------------------------------------------------------------------ stand-alone primitives (parity tests)

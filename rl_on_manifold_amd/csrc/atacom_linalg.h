@@ -78,6 +78,7 @@ template <> struct num<float> {
         *c = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, co) ^ ((unsigned)((q + 1) & 2) << 30));
     }
 #endif
+    static __device__ __forceinline__ float acos(float x) { return acosf(x); }
     static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
     static __device__ __forceinline__ float min(float a, float b) { return fminf(a, b); }
 };
@@ -91,6 +92,7 @@ template <> struct num<double> {
     static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
     static __device__ __forceinline__ double tanh(double x) { return ::tanh(x); }
     static __device__ __forceinline__ void sincos(double x, double* s, double* c) { ::sincos(x, s, c); }
+    static __device__ __forceinline__ double acos(double x) { return ::acos(x); }
     static __device__ __forceinline__ double max(double a, double b) { return fmax(a, b); }
     static __device__ __forceinline__ double min(double a, double b) { return fmin(a, b); }
 };

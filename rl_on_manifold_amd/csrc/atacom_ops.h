@@ -32,6 +32,20 @@ struct EnvOps {
                   hipStream_t s);
 };
 
+// Row N4: the rigid-body kernels of the iiwa environment live in their own translation unit (atacom_iiwa_dyn.hip)
+struct DynOps {
+    void (*step)(const atacom_config&, int lanes, void* f, int* ip, const void* act, void* obs, void* rew, uint8_t* ab,
+                 uint8_t* last, hipStream_t s);
+    void (*rollout)(const atacom_config&, int lanes, int n_steps, void* f, int* ip, const void* acts, void* obs,
+                    void* nobs, void* rew, uint8_t* ab, uint8_t* last, void* rec, int rec_ld, hipStream_t s);
+    void (*get_aux)(const atacom_config&, const void* f, void* out, hipStream_t s);
+    void (*set_aux)(const atacom_config&, void* f, const void* in, hipStream_t s);
+    void (*inverse_dynamics)(int n, const void* q, const void* dq, const void* ddq, void* tau, void* M, hipStream_t s);
+    void (*forward_dynamics)(int n, const void* q, const void* dq, const void* tau6, const void* ddq_aux, int use_damping,
+                             void* ddq6, hipStream_t s);
+};
+const DynOps* ops_iiwa_dyn(int dtype);
+
 const EnvOps* ops_circle(int dtype);
 const EnvOps* ops_circle_ec(int dtype);
 const EnvOps* ops_circle_t(int dtype);

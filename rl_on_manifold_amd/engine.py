@@ -33,7 +33,8 @@ class BatchedAtacomEnv:
 
     def __init__(self, env, batch, device='cuda:0', dtype=torch.float32, horizon=None, gamma=None, Kc=None,
                  time_step=None, n_intermediate_steps=None, action_penalty=None, auto_reset=False,
-                 hold_q=None, bias_mode='reference', rref_tol=None, lanes_per_env=0, term_tol=None, random_init=False, seed=0):
+                 hold_q=None, bias_mode='reference', rref_tol=None, lanes_per_env=0, term_tol=None, random_init=False, seed=0,
+                 dynamics_mode='kinematic'):
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.AtacomError("BatchedAtacomEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -67,6 +68,9 @@ class BatchedAtacomEnv:
             cfg.term_tol = float(term_tol)
         cfg.random_init = int(bool(random_init))     # device-side random reset (circle_base.py:36-42, env_hitting.py:24-25)
         cfg.seed = int(seed) & 0x7fffffff
+        # 'kinematic': q'' integrates directly (default); 'rigid_body' (iiwa, row N4): inverse dynamics -> torque ->
+        # forward dynamics with the URDF inertias / damping and the joint-7 / universal-joint servos
+        cfg.dynamics_mode = {'kinematic': 0, 'rigid_body': 1}[dynamics_mode]
         d = _lib.get_dims(self.env_id)
         self.dims = {'q': d.dim_q, 'f': d.n_f, 'g': d.n_g, 'null': d.n_null, 'c': d.n_f + d.n_g}   # atacom.py:25-40
         self.obs_dim, self.state_dim, self.init_state_dim = d.obs_dim, d.state_dim, d.init_state_dim
@@ -242,6 +246,16 @@ class BatchedAtacomEnv:
         st = self._as_dev(state, (self.batch, self.state_dim))
         _lib.check(self._lib.atacom_set_state(self._h, _ptr(st), self._stream()))
 
+    def get_aux_state(self):
+        """Servo joints of the rigid-body mode (iiwa): [B, 6] = [q7, qu1, qu2, dq7, dqu1, dqu2]."""
+        aux = torch.empty((self.batch, 6), device=self.device, dtype=self.dtype)
+        _lib.check(self._lib.atacom_get_aux_state(self._h, _ptr(aux), self._stream()))
+        return aux
+
+    def set_aux_state(self, aux):
+        a = self._as_dev(aux, (self.batch, 6))
+        _lib.check(self._lib.atacom_set_aux_state(self._h, _ptr(a), self._stream()))
+
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
             self._lib.atacom_destroy(self._h)
@@ -353,3 +367,35 @@ def constraint_terms(env, q, dq, bias_mode='reference'):
     with torch.cuda.device(q.device):
         _lib.check(lib.atacom_constraint_terms(C.byref(cfg), n, _ptr(q), _ptr(dq), _ptr(fun), _ptr(J), _ptr(b), stream))
     return fun, J, b
+
+
+def inverse_dynamics(q, dq, ddq, want_mass_matrix=False):
+    """Row N4 primitive: tau = M(q) ddq + C(q, dq) dq + g(q) of the nine-joint iiwa + striker chain on the GPU
+    (what the reference asks PyBullet for, iiwa_hit_atacom.py:58-63).  q, dq, ddq [n, 9]; returns tau [n, 9]
+    (and M [n, 9, 9])."""
+    lib = _lib.load()
+    n = q.shape[0]
+    q, dq, ddq = q.contiguous(), dq.contiguous(), ddq.contiguous()
+    dt = {torch.float32: _lib.F32, torch.float64: _lib.F64}[q.dtype]
+    tau = torch.empty((n, 9), device=q.device, dtype=q.dtype)
+    M = torch.empty((n, 9, 9), device=q.device, dtype=q.dtype) if want_mass_matrix else None
+    stream = C.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+    with torch.cuda.device(q.device):
+        _lib.check(lib.atacom_inverse_dynamics(dt, n, _ptr(q), _ptr(dq), _ptr(ddq), _ptr(tau), _ptr(M), stream))
+    return (tau, M) if want_mass_matrix else tau
+
+
+def forward_dynamics(q, dq, tau6, ddq_aux=None, damping=True):
+    """Row N4 primitive: accelerations [n, 6] of the controlled joints under torques tau6 [n, 6]; the servo joints follow
+    ddq_aux [n, 3] (None = at rest)."""
+    lib = _lib.load()
+    n = q.shape[0]
+    q, dq, tau6 = q.contiguous(), dq.contiguous(), tau6.contiguous()
+    aux = None if ddq_aux is None else ddq_aux.contiguous()
+    dt = {torch.float32: _lib.F32, torch.float64: _lib.F64}[q.dtype]
+    out = torch.empty((n, 6), device=q.device, dtype=q.dtype)
+    stream = C.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+    with torch.cuda.device(q.device):
+        _lib.check(lib.atacom_forward_dynamics(dt, n, _ptr(q), _ptr(dq), _ptr(tau6), _ptr(aux), int(bool(damping)), _ptr(out),
+                                               stream))
+    return out

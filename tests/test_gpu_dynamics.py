@@ -1,0 +1,160 @@
+"""Row N4 on the GPU: rigid-body dynamics of the iiwa + striker chain (inverse dynamics / mass matrix / forward
+dynamics primitives, golden set G11 = the reference's URDF) and the opt-in rigid-body env step against the oracle."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import atacom_scalar as osc          # noqa: E402
+from oracle import atacom_batched as ob          # noqa: E402
+from oracle import dynamics as D                 # noqa: E402
+
+DEV = 'cuda:0'
+DT = {'f64': torch.float64, 'f32': torch.float32}
+IIWA_INIT_Q = np.array([0.0, 0.7135214629060707, 0.0, -0.5024756033561426, 0.0, 1.9256631778550268])
+
+
+@pytest.mark.parametrize('dt', ['f64', 'f32'])
+def test_inverse_dynamics_and_mass_matrix_against_the_reference_urdf(golden, dt):
+    """tau = M ddq + C dq + g and M(q) of the nine-joint chain vs the reference's URDF evaluated link by link (G11).
+    float64 1e-10; float32 2e-4 abs on torques of up to ~150 Nm (relative 1e-6), 1e-5 on M entries (composite inertias
+    are accumulated about the world origin: m |c|^2 ~ 40 kg m^2 terms cancel down to entries <= ~6 kg m^2)."""
+    from rl_on_manifold_amd import inverse_dynamics
+    g = golden('iiwa_urdf')
+    t = lambda a: torch.tensor(a, device=DEV, dtype=DT[dt])                   # noqa: E731
+    tau, M = inverse_dynamics(t(g['dyn_q']), t(g['dyn_dq']), t(g['dyn_ddq']), want_mass_matrix=True)
+    tau, M = tau.cpu().numpy().astype(np.float64), M.cpu().numpy().astype(np.float64)
+    tol_tau, tol_M = (1e-10, 1e-10) if dt == 'f64' else (2e-4, 1e-5)
+    assert np.abs(tau - g['dyn_tau']).max() < tol_tau
+    assert np.abs(M - g['dyn_M']).max() < tol_M
+    assert np.abs(M - np.swapaxes(M, 1, 2)).max() == 0.0                      # symmetric by construction
+    assert np.linalg.eigvalsh(M).min() > 1e-4                                 # positive definite
+    grav = inverse_dynamics(t(g['dyn_q']), t(0 * g['dyn_dq']), t(0 * g['dyn_ddq'])).cpu().numpy()
+    assert np.abs(grav - g['dyn_gravity']).max() < tol_tau
+
+
+@pytest.mark.parametrize('dt', ['f64', 'f32'])
+def test_inverse_then_forward_dynamics_is_the_identity(dt):
+    """ID o FD = identity on the controlled joints (servo joints at rest, damping off) -- the assumption the default
+    kinematic mode makes is exact here; with damping on, the acceleration drops by M_aa^-1 D dq."""
+    from rl_on_manifold_amd import inverse_dynamics, forward_dynamics
+    rng = np.random.default_rng(4)
+    n = 1000
+    q = rng.uniform(-1.5, 1.5, (n, 9)); dq = rng.uniform(-1.5, 1.5, (n, 9)); dq[:, 6:] = 0
+    dd = np.concatenate([rng.uniform(-10, 10, (n, 6)), np.zeros((n, 3))], 1)
+    t = lambda a: torch.tensor(a, device=DEV, dtype=DT[dt])                   # noqa: E731
+    tau = inverse_dynamics(t(q), t(dq), t(dd))
+    back = forward_dynamics(t(q), t(dq), tau[:, :6].contiguous(), None, damping=False).cpu().numpy()
+    assert np.abs(back - dd[:, :6]).max() < (1e-9 if dt == 'f64' else 2e-2)    # float32: cond(M_aa) ~ 1e4 on 10 rad/s^2
+    damped = forward_dynamics(t(q), t(dq), tau[:, :6].contiguous(), None, damping=True).cpu().numpy()
+    ref = D.forward_dynamics(q, dq, tau.cpu().numpy().astype(np.float64)[:, :6], np.zeros((n, 3)))
+    assert np.abs(damped - ref).max() < (1e-8 if dt == 'f64' else 2e-2)
+    assert np.abs(damped - back).max() > 1e-2                                 # the damping really acts
+    # prescribed servo accelerations couple into the arm
+    aux = rng.uniform(-20, 20, (n, 3))
+    coupled = forward_dynamics(t(q), t(dq), tau[:, :6].contiguous(), t(aux), damping=True).cpu().numpy()
+    ref = D.forward_dynamics(q, dq, tau.cpu().numpy().astype(np.float64)[:, :6], aux)
+    assert np.abs(coupled - ref).max() < (1e-8 if dt == 'f64' else 2e-2)
+
+
+def test_passive_dynamics_energy_budget():
+    """Energy drift is bounded and of integrator order: the undriven, undamped chain (tau = 0) integrated with the engine's
+    semi-implicit Euler conserves E = T + V up to an error that halves with the step; with the URDF damping the energy
+    only goes down."""
+    from rl_on_manifold_amd import forward_dynamics
+    rng = np.random.default_rng(7)
+    n = 256
+    q = np.concatenate([IIWA_INIT_Q + rng.normal(0, 0.2, (n, 6)), np.zeros((n, 3))], 1)
+    dq = np.concatenate([rng.normal(0, 0.3, (n, 6)), np.zeros((n, 3))], 1)
+
+    def run(h, steps, damping):
+        qq, dd = q.copy(), dq.copy()
+        e0 = sum(D.energy(qq, dd))
+        worst = np.zeros(n)
+        for _ in range(steps):
+            acc = forward_dynamics(torch.tensor(qq, device=DEV), torch.tensor(dd, device=DEV),
+                                   torch.zeros((n, 6), device=DEV, dtype=torch.float64), None, damping=damping).cpu().numpy()
+            dd[:, :6] += acc * h
+            qq[:, :6] += dd[:, :6] * h
+            worst = np.maximum(worst, np.abs(sum(D.energy(qq, dd)) - e0))
+        return e0, sum(D.energy(qq, dd)), worst
+
+    e0, e1, drift = run(1.0 / 240.0, 30, False)              # 1/8 s of free fall
+    _, _, drift_half = run(1.0 / 480.0, 60, False)
+    scale = np.abs(e0).max()
+    assert np.median(drift) < 5e-3 * scale and drift.max() < 0.05 * scale
+    assert np.median(drift_half / np.maximum(drift, 1e-12)) < 0.65          # first order in the step
+    e0, e1, _ = run(1.0 / 240.0, 30, True)
+    assert (e1 <= e0 + 1e-3 * scale).all() and (e1 < e0 - 1e-5).mean() > 0.9
+
+
+def _aux(o):
+    return np.concatenate([o.qx, o.dqx], 1)
+
+
+@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('dt', ['f64', 'f32'])
+def test_rigid_body_env_step_against_oracle(dt, lanes):
+    """dynamics_mode = 'rigid_body': the whole env step (ATACOM projection, inverse dynamics, effort saturation, servo
+    joints, hybrid forward dynamics, integration) vs the oracle, teacher-forced incl. the servo-joint state."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_parity import _full_state
+    from parity_tools import SensitivityRecorder
+    from rl_on_manifold_amd import BatchedAtacomEnv
+    spec = osc.iiwa_spec(dynamics_mode=1)
+    B, T = 256, 30
+    env = BatchedAtacomEnv('iiwa', B, device=DEV, dtype=DT[dt], lanes_per_env=lanes, dynamics_mode='rigid_body')
+    rng = np.random.default_rng(3)
+    o = ob.BatchedAtacomEnv(spec, B, init_q=IIWA_INIT_Q + rng.normal(0, 0.05, (B, 6)))
+
+    def outputs(p, inputs):
+        oo, orr, oab, _ = p.step(inputs[0])
+        return np.concatenate([oo, p.s, p.qx, p.dqx, orr[:, None]], 1)
+
+    rec = SensitivityRecorder(outputs, seed=2, state_fields=('q', 'dq', 's', 'puck', 'qx', 'dqx'))
+    moved = 0.0
+    for t in range(T):
+        a = rng.uniform(-1.2, 1.2, (B, 5))
+        env.set_state(_full_state(env, o))
+        env.set_aux_state(_aux(o))
+        obs, r, ab, _ = env.step(a)
+        nq, ng = 6, 11
+        s_dev = env.get_state().cpu().numpy()[:, 2 * nq:2 * nq + ng]
+        dev = np.concatenate([obs.cpu().numpy(), s_dev, env.get_aux_state().cpu().numpy(), r.cpu().numpy()[:, None]], 1)
+        if dt == 'f32':
+            rec.record(o, (a,), dev)
+        oo, orr, oab, _ = o.step(a)
+        if dt == 'f64':
+            ref = np.concatenate([oo, o.s, o.qx, o.dqx, orr[:, None]], 1)
+            assert np.abs(dev - ref).max() < 1e-8, np.abs(dev - ref).max()
+        moved = max(moved, np.abs(o.qx).max())
+    assert moved > 1e-3                                  # the servo joints really move
+    if dt == 'f32':
+        print(rec.finish('rigid-body step lanes %d' % lanes))
+    # and the mode is not a no-op: the kinematic engine lands elsewhere
+    kin = BatchedAtacomEnv('iiwa', B, device=DEV, dtype=DT[dt], lanes_per_env=lanes)
+    kin.set_state(_full_state(kin, o)); env.set_state(_full_state(env, o)); env.set_aux_state(_aux(o))
+    a = rng.uniform(-1, 1, (B, 5))
+    d = (kin.step(a)[0] - env.step(a)[0]).abs().max().item()
+    assert d > 1e-4
+
+
+def test_rigid_body_rollout_equals_steps_and_keeps_the_constraints():
+    """k_rollout in rigid-body mode == the same steps one launch at a time; ATACOM still holds the constraints."""
+    from rl_on_manifold_amd import BatchedAtacomEnv
+    B, T = 512, 60
+    g = torch.Generator(device=DEV).manual_seed(0)
+    acts = torch.rand((T, B, 5), device=DEV, generator=g) * 2 - 1
+    e1 = BatchedAtacomEnv('iiwa', B, device=DEV, dynamics_mode='rigid_body', auto_reset=True, horizon=25)
+    e2 = BatchedAtacomEnv('iiwa', B, device=DEV, dynamics_mode='rigid_body', auto_reset=True, horizon=25)
+    out = e1.rollout(acts)
+    for t in range(T):
+        obs, r, ab, info = e2.step(acts[t])
+        assert torch.allclose(obs, out['next_obs'][t], atol=2e-5) and torch.equal(info['last'], out['last'][t].bool())
+    assert torch.allclose(e1.get_aux_state(), e2.get_aux_state(), atol=2e-5)
+    c_avg, c_max, c_dq = e1.get_constraints_logs()
+    assert c_max < 0.02 and c_dq < 0.0
+    with pytest.raises(Exception):
+        BatchedAtacomEnv('planar', 8, device=DEV, dynamics_mode='rigid_body')

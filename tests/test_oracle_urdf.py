@@ -95,3 +95,52 @@ def test_oracle_constraint_terms_against_the_reference_urdf(golden):
         fun, J, b = expected_terms(g, bias)
         fo, Jo, bo = ob.constraint_terms(osc.iiwa_spec(bias_mode=bias), g['q'], g['dq'])
         assert np.abs(fo - fun).max() < 1e-13 and np.abs(Jo - J).max() < 1e-13 and np.abs(bo - b).max() < 1e-12
+
+
+def test_oracle_dynamics_against_the_reference_urdf(golden):
+    """Row N4, golden set G11: inverse dynamics, mass matrix and energies of the nine-joint chain computed by the generic
+    evaluator from the reference's URDF, link by link, vs oracle/dynamics.py on the merged-body constants."""
+    from oracle import dynamics as D
+    g = golden('iiwa_urdf')
+    q, dq, ddq = g['dyn_q'], g['dyn_dq'], g['dyn_ddq']
+    assert np.abs(D.rnea(q, dq, ddq) - g['dyn_tau']).max() < 1e-11
+    assert np.abs(D.rnea(q, 0 * dq, 0 * dq) - g['dyn_gravity']).max() < 1e-11
+    M = D.mass_matrix(q)
+    assert np.abs(M - g['dyn_M']).max() < 1e-12
+    assert np.abs(M - np.swapaxes(M, 1, 2)).max() < 1e-15 and np.linalg.eigvalsh(M).min() > 1e-4     # symmetric positive definite
+    kin, pot = D.energy(q, dq)
+    assert np.abs(kin - g['dyn_energy'][:, 0]).max() < 1e-12
+    assert np.ptp(pot - g['dyn_energy'][:, 1]) < 1e-11          # up to the constant of the fixed base link (link_0)
+    assert np.allclose(g['damping'], D.II.DAMPING)
+    # inverse dynamics followed by forward dynamics is the identity (no damping, servo joints at rest)
+    dd = np.concatenate([ddq[:, :6], np.zeros((len(q), 3))], 1)
+    tau = D.rnea(q, dq, dd)
+    back = D.forward_dynamics(q, dq, tau[:, :6], np.zeros((len(q), 3)), damping=np.zeros(9))
+    assert np.abs(back - ddq[:, :6]).max() < 1e-10
+    # damping only ever removes energy: with tau = gravity compensation the kinetic energy cannot grow
+    rng = np.random.default_rng(0)
+    qq, dd_ = q[:8].copy(), dq[:8].copy()
+    dd_[:, 6:] = 0.0
+    e0 = D.energy(qq, dd_)[0]
+    for _ in range(50):
+        grav = D.rnea(qq, 0 * dd_, 0 * dd_)[:, :6]
+        coriolis = D.rnea(qq, dd_, 0 * dd_)[:, :6] - grav
+        acc = D.forward_dynamics(qq, dd_, grav + coriolis * 0, np.zeros((8, 3)))
+        dd_[:, :6] += acc / 240.0
+        qq[:, :6] += dd_[:, :6] / 240.0
+    assert (D.energy(qq, dd_)[0] <= e0 * (1 + 1e-3) + 1e-9).all()
+
+
+def test_servo_targets():
+    """env_single.py:137-185: at the reset pose (tip pointing straight down, R = diag(-1, 1, -1)) both servos rest at 0;
+    tilting the last link tilts the universal joint by the same angle."""
+    from oracle import dynamics as D
+    q0 = np.array([[0.0, 0.7135214629060707, 0.0, -0.5024756033561426, 0.0, 1.9256631778550268, 0.0]])
+    assert np.abs(D.joint7_target(q0[:, :6], np.zeros(1))).max() < 1e-3
+    assert np.abs(D.universal_joint_target(q0)).max() < 1e-3
+    q1 = q0.copy(); q1[0, 5] += 0.3
+    u = D.universal_joint_target(q1)
+    assert abs(abs(u[0, 0]) - 0.3) < 2e-3 and u[0, 1] == 0.0
+    q2 = q0.copy(); q2[0, 4] = 0.7                       # rolling joint 5 turns the striker's y axis: joint 7 compensates
+    t7 = D.joint7_target(q2[:, :6], np.zeros(1))
+    assert 0.05 < abs(t7[0]) < np.pi / 2
