@@ -60,15 +60,19 @@ const atacom::EnvOps* get_ops(int env_id, int dtype) {
 
 constexpr int kStatBlocks = 256;
 
-// kernel mapping policy for lanes_per_env = 0, from measurements on MI355X (profiles/r01_lanes_vs_batch.md): the
-// fewer lanes an environment is spread over, the fewer instructions in total but the more per wave; a mapping's step
-// time is flat while its waves still find a SIMD each (1024 SIMDs) and doubles beyond.  So: the widest mapping whose
-// waves fit -- quad up to 16384 envs (1024 waves), pair up to 32768, lane beyond.
+// kernel mapping policy for lanes_per_env = 0, from measurements on MI355X (profiles/r02_lanes_vs_batch.md): the fewer
+// lanes an environment is spread over, the fewer instructions in total but the more per wave; a mapping's step time is
+// flat while its waves still find a SIMD each (1024 SIMDs) and doubles beyond.  So: the widest mapping whose waves fit --
+// quad up to 16384 envs (1024 waves), pair up to 32768, lane beyond; the 8-lane mapping (12 % fewer instructions per wave
+// than the quad) pays off only while it leaves half the chip idle (iiwa, <= 4096 envs: 26.7 vs 29.0 us) -- with every
+// CU busy the clock drops by ~5 % and the gain is gone (8192 envs: 29.3 vs 29.5 us).
 int pick_lanes(const atacom_config& c) {
     if (c.lanes_per_env == 1 || c.lanes_per_env == 2 || c.lanes_per_env == 4 || c.lanes_per_env == 8)
         return c.lanes_per_env;
     if (c.dtype == ATACOM_F64) return 1;
-    if (c.env_id == ATACOM_ENV_IIWA || c.env_id == ATACOM_ENV_PLANAR)      // iiwa: 30 / 40 / 52 us per step
+    if (c.env_id == ATACOM_ENV_IIWA)                                       // 27 / 29.5 / 40 / 52 us per step
+        return c.batch <= 4096 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));
+    if (c.env_id == ATACOM_ENV_PLANAR)
         return c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1);
     return 1;                                                              // circle: launch-bound either way
 }

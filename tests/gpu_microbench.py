@@ -8,7 +8,8 @@ tag = os.environ.get('ATACOM_LIB', 'default')
 for name in sys.argv[1:] or ['iiwa']:
     for B in [int(x) for x in os.environ.get("MB_BATCHES", "8192").split(",")]:
       for lanes in [int(x) for x in os.environ.get("MB_LANES", "1,4").split(",")]:
-        env = BatchedAtacomEnv(name, B, device=dev, dtype=torch.float32, auto_reset=True, lanes_per_env=lanes)
+        env = BatchedAtacomEnv(name, B, device=dev, dtype=torch.float32, auto_reset=True, lanes_per_env=lanes,
+                               dynamics_mode=os.environ.get('MB_DYN', 'kinematic'))
         k = env.dims['null']
         gen = torch.Generator(device=dev); gen.manual_seed(0)
         st = env.get_state(); nq = env.dims['q']

@@ -16,8 +16,9 @@ the kernel's ~10^4 rounded operations can reach); if the float64 oracle itself t
 otherwise the test FAILS.  Nothing is waved through by a percentage: a kernel bug (wrong lane, wrong row, stale
 register) produces errors where the oracle is insensitive and is caught on the first sample.
 
-C = 10 and floor = 5e-6 * max(1, |value|) are calibrated on 4.1e5 teacher-forced env steps per environment
-(profiles/r02_parity_sensitivity.md): the largest err / sens ratio seen was 8.9, the median 0.01.
+C = 4 and floor = 5e-6 * max(1, |value|) are calibrated on 1.6e5 teacher-forced env steps per environment and kernel
+mapping (profiles/r02_parity_sensitivity.md): the largest err / sens seen was 1.7, the 99.9th percentile 0.09, the
+median below 0.01 -- the bound is a worst-case (condition-number) bound, the bulk of the errors sits at 1e-6.
 """
 import copy
 
@@ -25,7 +26,8 @@ import numpy as np
 
 QUICK_SCALES = (2e-7, 1e-6, 4e-6)
 DEEP_SCALES = (1e-6, 4e-6, 1.6e-5)
-C_SENS = 10.0
+C_SENS = 4.0
+JC_NOISE_FRACTION = 0.25     # J_c entries are perturbed at a quarter of the input scales: 5e-8 ... 1e-6 (1 to 16 float32 ulps)
 FLOOR = 5e-6
 
 
@@ -53,7 +55,7 @@ def perturbed(o, scale, rng, fields=('q', 'dq', 's', 'puck')):
     # a float32 factorisation is exactly that, and the reference's LAPACK null basis responds to it with an amplification
     # of up to ~1e5 when joints sit near zero (nearly decoupled joint-limit rows: a near-breakdown of the Golub-Kahan
     # recurrence) -- see DESIGN.md section 2 and profiles/r02_parity_sensitivity.md
-    p.jc_noise = (scale, rng)
+    p.jc_noise = (scale * JC_NOISE_FRACTION, rng)
     return p
 
 
@@ -133,7 +135,7 @@ class SensitivityRecorder:
                    '%d samples needed the deep probe' % (what, E.size, np.median(E), np.quantile(E, 0.999), E.max(),
                                                          ratio.max(), n_deep))
         assert not unexplained, 'UNEXPLAINED float32 errors (t, env, err, sens, where): %s | %s' % (unexplained[:10], summary)
-        assert np.median(E) < 2e-5, summary            # and the bulk is at rounding level
+        assert np.median(E) < 2e-5 and np.quantile(E, 0.99) < 2e-3, summary      # and the bulk is at rounding level
         return summary
 
 
@@ -152,7 +154,7 @@ def assert_matrix_fn_explained(fn, A, dev_out, what='', seed=0):
             for _ in range(draws):
                 Ai = A[idx]
                 Ap = Ai * (1.0 + sc * rng.choice([-1.0, 1.0], Ai.shape)) \
-                    + sc * np.abs(Ai).max((1, 2), keepdims=True) * rng.choice([-1.0, 1.0], Ai.shape)
+                    + JC_NOISE_FRACTION * sc * np.abs(Ai).max((1, 2), keepdims=True) * rng.choice([-1.0, 1.0], Ai.shape)
                 out = fn(Ap).reshape(len(idx), -1)
                 s = np.maximum(s, (np.abs(out - base[idx]) / scale[idx]).max(1))
         return s
