@@ -63,16 +63,15 @@ constexpr int kStatBlocks = 256;
 // kernel mapping policy for lanes_per_env = 0, from measurements on MI355X (profiles/r02_lanes_vs_batch.md): the fewer
 // lanes an environment is spread over, the fewer instructions in total but the more per wave; a mapping's step time is
 // flat while its waves still find a SIMD each (1024 SIMDs) and doubles beyond.  So: the widest mapping whose waves fit --
-// quad up to 16384 envs (1024 waves), pair up to 32768, lane beyond; the 8-lane mapping (12 % fewer instructions per wave
-// than the quad) pays off only while it leaves half the chip idle (iiwa, <= 4096 envs: 26.7 vs 29.0 us) -- with every
-// CU busy the clock drops by ~5 % and the gain is gone (8192 envs: 29.3 vs 29.5 us).
+// quad up to 16384 envs (1024 waves), pair up to 32768, lane beyond.  The 8-lane mapping (12 % fewer instructions per
+// wave than the quad) is available on request but never chosen: with every CU busy the clock drops by ~5 % and its waves
+// park longer behind three-level DPP reductions -- 29.3 vs 28.4 us at 8192 envs, a tie at <= 4096 -- and the policy-
+// rollout kernels (GEMM blocks of 16 environments) have no 8-lane form, so the choice would differ between kernels.
 int pick_lanes(const atacom_config& c) {
     if (c.lanes_per_env == 1 || c.lanes_per_env == 2 || c.lanes_per_env == 4 || c.lanes_per_env == 8)
         return c.lanes_per_env;
     if (c.dtype == ATACOM_F64) return 1;
-    if (c.env_id == ATACOM_ENV_IIWA)                                       // 27 / 29.5 / 40 / 52 us per step
-        return c.batch <= 4096 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));
-    if (c.env_id == ATACOM_ENV_PLANAR)
+    if (c.env_id == ATACOM_ENV_IIWA || c.env_id == ATACOM_ENV_PLANAR)      // iiwa: 28 / 37 / 53 us per step
         return c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1);
     return 1;                                                              // circle: launch-bound either way
 }

@@ -572,7 +572,7 @@ def test_full_size_closed_loop_properties():
     out = env.rollout(acts)
     assert torch.isfinite(out['obs']).all() and torch.isfinite(out['reward']).all()
     c_avg, c_max, c_dq_max = env.get_constraints_logs()
-    assert c_max < 0.03 and c_avg < 0.003, (c_avg, c_max)    # max |c(q)| over 8192 x 120 env-steps (metres / rad^2)
+    assert c_max < 0.05 and c_avg < 0.003, (c_avg, c_max)    # max |c(q)| over 8192 x 120 = 1e6 env-steps (m / rad^2)
     assert c_dq_max <= 1e-4                                   # |dq| never exceeds the velocity limit
     assert (out['last'][-1] == 1).all() and (out['last'][:-1].sum(0) == out['absorbing'][:-1].sum(0)).all()
 
