@@ -89,6 +89,10 @@ typedef struct atacom_config {
                                      joints follow the forward dynamics under it with the URDF joint damping, joint 7 and
                                      the striker's universal joint riding position servos (env_single.py:137-185) */
     int32_t reserved0;
+    double dt_base;               /* time step of the BASE environment's integrator when it differs from `dt` (0 = same).
+                                     The reference's CircleEnvAtacom / CircleEnvErrorCorrection hand time_step to the wrapper
+                                     only -- slack integration, atacom.py:135 -- while the base CircularMotion keeps its
+                                     default 0.01 (circle_atacom.py:7-18, circle_base.py:18-19,62-63): defaults reproduce that */
 } atacom_config;
 
 typedef struct atacom_handle atacom_handle;

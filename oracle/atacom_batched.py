@@ -344,8 +344,8 @@ class BatchedAtacomEnv:
             dq_pre = np.abs(self.dq) - 1.0
             self._log(c_pre.max(-1), c_pre.max(-1), dq_pre.max(-1))
             a = alpha * 10.0
-            self.q = self.q + (self.dq * sp.dt + a * sp.dt ** 2 / 2)
-            self.dq = self.dq + a * sp.dt
+            self.q = self.q + (self.dq * sp.dt_base + a * sp.dt_base ** 2 / 2)
+            self.dq = self.dq + a * sp.dt_base
             absorbing = np.maximum(c_pre.max(-1), dq_pre.max(-1)) > sp.term_tol
             reward = np.where(absorbing, -100.0, np.exp(-np.hypot(1.0 - self.q[:, 0], self.q[:, 1])))
         elif sp.env_id == ENV_CIRCLE:
@@ -356,8 +356,8 @@ class BatchedAtacomEnv:
             self.s = self.s + mu[:, nq:] * sp.dt
             ddq = self.acc_truncation(self.dq, mu[:, :nq])
             a = np.clip(ddq / sp.acc_max, -1.0, 1.0) * 10.0
-            self.q = self.q + (self.dq * sp.dt + a * sp.dt ** 2 / 2)
-            self.dq = self.dq + a * sp.dt
+            self.q = self.q + (self.dq * sp.dt_base + a * sp.dt_base ** 2 / 2)
+            self.dq = self.dq + a * sp.dt_base
             reward = np.exp(-np.hypot(1.0 - self.q[:, 0], self.q[:, 1]))
             absorbing = np.zeros(self.B, dtype=bool)
         else:

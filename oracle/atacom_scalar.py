@@ -55,8 +55,15 @@ class EnvSpec:
     mode: int = 0            # MODE_*
     term_tol: float = 0.1    # circle_terminated.py:13
     base_xy: np.ndarray = field(default_factory=lambda: np.zeros(2))
+    base_dt: float = 0.0     # time step of the BASE env when it differs from the wrapper's (quirk Q4: CircleEnvAtacom /
+                             # CircleEnvErrorCorrection hand time_step to the wrapper only, circle_atacom.py:7-18 -- the
+                             # base CircularMotion keeps its default 0.01); 0 = same as dt
     dynamics_mode: int = 0   # 0: inverse o forward dynamics = identity; 1: rigid body (row N4, iiwa,
                              # oracle/dynamics.py -- implemented by the batched oracle only)
+
+    @property
+    def dt_base(self):
+        return self.base_dt if self.base_dt > 0 else self.dt
 
     @property
     def n_c(self):
@@ -76,10 +83,11 @@ class EnvSpec:
 
 
 def circle_spec(horizon=500, gamma=0.99, Kc=100.0, dt=0.01):
-    """circle_atacom.py:7-18."""
+    """circle_atacom.py:7-18.  `dt` is the WRAPPER's time_step; the base CircularMotion is built without it and keeps
+    its default 0.01 (quirk Q4)."""
     return EnvSpec(ENV_CIRCLE, 2, 1, 1, K=np.array([0.1, 2.0]), Kc=np.full(2, float(Kc)),
                    vel_max=np.ones(2), acc_max=np.full(2, 10.0), Kq=np.full(2, 20.0), dt=dt,
-                   substeps=1, horizon=horizon, gamma=gamma, obs_dim=4, hold_q=False)
+                   substeps=1, horizon=horizon, gamma=gamma, obs_dim=4, hold_q=False, base_dt=0.01)
 
 
 def circle_ec_spec(horizon=500, gamma=0.99, Kc=100.0, dt=0.01):
@@ -93,6 +101,7 @@ def circle_t_spec(horizon=500, gamma=0.99, dt=0.01, tol=0.1):
     """CircleEnvTerminated, circle_terminated.py:8-29 (no wrapper at all)."""
     sp = circle_spec(horizon, gamma, 100.0, dt)
     sp.mode = MODE_TERMINATED
+    sp.base_dt = dt                 # here time_step does reach the base env (circle_terminated.py:13-14)
     sp.term_tol = tol
     return sp
 
@@ -299,8 +308,8 @@ class ScalarAtacomEnv:
                               abs(self.dq[0]) - 1, abs(self.dq[1]) - 1])
             self.logs.append(c_pre)
             a = alpha * 10.0
-            self.q = self.q + (self.dq * sp.dt + a * sp.dt ** 2 / 2)
-            self.dq = self.dq + a * sp.dt
+            self.q = self.q + (self.dq * sp.dt_base + a * sp.dt_base ** 2 / 2)
+            self.dq = self.dq + a * sp.dt_base
             reward = float(np.exp(-np.linalg.norm(np.array([1.0, 0.0]) - self.q)))
             absorbing = bool(np.any(c_pre > sp.term_tol))
             if absorbing:
@@ -318,8 +327,8 @@ class ScalarAtacomEnv:
             ddq = acc_truncation(sp, self.dq, mu[:nq])                              # :137
             ctrl = ddq / sp.acc_max                                                 # circle_atacom.py:26-27
             a = np.clip(ctrl, -1.0, 1.0) * 10.0                                     # circle_base.py:59-60
-            self.q = self.q + (self.dq * sp.dt + a * sp.dt ** 2 / 2)                  # :62
-            self.dq = self.dq + a * sp.dt                                           # :63
+            self.q = self.q + (self.dq * sp.dt_base + a * sp.dt_base ** 2 / 2)                  # :62
+            self.dq = self.dq + a * sp.dt_base                                           # :63
             reward = float(np.exp(-np.linalg.norm(np.array([1.0, 0.0]) - self.q)))  # :65
             absorbing = False
             dbg.append(mu)

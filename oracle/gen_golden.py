@@ -19,6 +19,7 @@ Golden sets:
   G6 tables         acc_truncation and _compute_slack_variables
   G7 logs           get_constraints_logs aggregation
   G9 baselines      CircleEnvErrorCorrection / CircleEnvTerminated trajectories (row N3)
+  G4b circle_dt     CircleEnvAtacom / CircleEnvErrorCorrection at time_step != 0.01 (quirk Q4: only the wrapper sees it)
   G8 policy         the reference's actor networks (examples/network.py) forward() on random inputs (row N2)
   G10 urdf          the reference's OWN iiwa_1.urdf evaluated by a generic URDF tree evaluator (oracle/urdf_model.py,
                     xml.etree -- no hand-unrolled constant): position, 6 x n LOCAL_WORLD_ALIGNED Jacobian, w x v and
@@ -460,6 +461,32 @@ def gen_policy():
     print('policy_net.npz', sorted(out)[:6], '...')
 
 
+def gen_circle_dt():
+    """Quirk Q4: CircleEnvAtacom(time_step=...) / CircleEnvErrorCorrection(time_step=...) hand time_step to the wrapper
+    only (slack integration); the base CircularMotion keeps 0.01.  Trajectories of the reference at time_step 0.02 / 0.004."""
+    from atacom.environments.circular_motion import CircleEnvErrorCorrection
+    rng = np.random.default_rng(77)
+    out = {}
+    for tag, cls, ts, k in (('A', CircleEnvAtacom, 0.02, 1), ('A2', CircleEnvAtacom, 0.004, 1), ('E', CircleEnvErrorCorrection, 0.02, 2)):
+        T, n = 200, 4
+        acts = rng.uniform(-1.2, 1.2, (n, T, k))
+        obs, ss, rew, s0 = [], [], [], []
+        for i in range(n):
+            env = cls(horizon=T, time_step=ts)
+            env.reset()
+            s0.append(env.s.copy())
+            o_, s_, r_ = [], [], []
+            for a in acts[i]:
+                o, r, ab, _ = env.step(a)
+                o_.append(o); s_.append(env.s.copy()); r_.append(r)
+            obs.append(o_); ss.append(s_); rew.append(r_)
+        out[tag + '_time_step'] = np.array(ts)
+        out[tag + '_actions'], out[tag + '_obs'], out[tag + '_s'] = acts, np.array(obs), np.array(ss)
+        out[tag + '_reward'], out[tag + '_s0'] = np.array(rew), np.array(s0)
+    np.savez_compressed(os.path.join(OUT, 'circle_time_step.npz'), **out)
+    print('circle_time_step.npz', out['A_obs'].shape)
+
+
 IIWA_URDF = '/root/reference/atacom/environments/iiwa_air_hockey/urdf/iiwa_1.urdf'
 
 
@@ -516,6 +543,6 @@ def gen_urdf():
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    todo = sys.argv[1:] or ['nullspace', 'constraints', 'circle', 'generic', 'tables', 'policy', 'baselines', 'urdf']
+    todo = sys.argv[1:] or ['nullspace', 'constraints', 'circle', 'generic', 'tables', 'policy', 'baselines', 'urdf', 'circle_dt']
     for name in todo:
         globals()['gen_' + name]()

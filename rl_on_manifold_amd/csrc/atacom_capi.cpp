@@ -156,6 +156,7 @@ int atacom_default_config(int32_t env_id, atacom_config* c) {
     if (env_id == ATACOM_ENV_CIRCLE || env_id == ATACOM_ENV_CIRCLE_EC || env_id == ATACOM_ENV_CIRCLE_T) {
         // circle_atacom.py:7-18 == circle_error_correction.py:8-21 (same constraints and gains)
         c->substeps = 1; c->horizon = 500; c->dt = 0.01; c->hold_q = 0;
+        c->dt_base = 0.01;           // circle_base.py:18: the wrappers never pass their time_step on (circle_atacom.py:8)
         c->K[0] = 0.1; c->K[1] = 2.0;
         for (int i = 0; i < 2; ++i) { c->Kc[i] = 100.0; c->vel_max[i] = 1.0; c->acc_max[i] = 10.0; c->Kq[i] = 20.0; }
     } else if (env_id == ATACOM_ENV_PLANAR) {

@@ -41,7 +41,7 @@ template <typename T>
 struct Params {
     int batch, substeps, horizon, hold_q, bias_mode, auto_reset, random_init, dynamics_mode;
     unsigned int seed;
-    T dt, rref_tol, action_penalty, alpha_max;
+    T dt, dt_base, rref_tol, action_penalty, alpha_max;      // dt_base: the base env's integrator step (circle quirk Q4)
     T K[12], Kc[12], vel_max[6], acc_max[6], Kq[6], pos_limit[6];
     T base_x, base_y;
     T link[3];

@@ -278,8 +278,8 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const T acc = alpha[i < NK ? i : 0] * T(10);                                   // circle_base.py:59-60
-            st.q[i] += num<T>::fma(st.dq[i], P.dt, acc * (P.dt * P.dt) / T(2));
-            st.dq[i] = num<T>::fma(acc, P.dt, st.dq[i]);
+            st.q[i] += num<T>::fma(st.dq[i], P.dt_base, acc * (P.dt_base * P.dt_base) / T(2));
+            st.dq[i] = num<T>::fma(acc, P.dt_base, st.dq[i]);
         }
         const T dxr = T(1) - st.q[0];
         const T rr = num<T>::exp(-num<T>::sqrt(num<T>::fma(dxr, dxr, st.q[1] * st.q[1])));
@@ -431,8 +431,9 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const T acc = num<T>::min(num<T>::max(num<T>::div(ddq[i], P.acc_max[i]), T(-1)), T(1)) * T(10);
-                st.q[i] += num<T>::fma(st.dq[i], P.dt, acc * (P.dt * P.dt) / T(2));
-                st.dq[i] = num<T>::fma(acc, P.dt, st.dq[i]);
+                // the BASE env's step (circle_base.py:62-63): dt_base, not the wrapper's dt (quirk Q4)
+                st.q[i] += num<T>::fma(st.dq[i], P.dt_base, acc * (P.dt_base * P.dt_base) / T(2));
+                st.dq[i] = num<T>::fma(acc, P.dt_base, st.dq[i]);
             }
         } else {
             if constexpr (DYN && E::ID == 2) rigid_body_substep<T, E>(P, st, ddq);      // row N4: ddq <- forward dynamics

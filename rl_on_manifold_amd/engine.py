@@ -53,6 +53,9 @@ class BatchedAtacomEnv:
             cfg.gamma = float(gamma)
         if time_step is not None:
             cfg.dt = float(time_step)
+            if self.env_id == _lib.ENV_CIRCLE_T:
+                cfg.dt_base = float(time_step)      # CircularMotion itself takes time_step (circle_terminated.py:13-14);
+            # CircleEnvAtacom / CircleEnvErrorCorrection keep the base env at its default 0.01 (quirk Q4, dt_base untouched)
         if n_intermediate_steps is not None:
             cfg.substeps = int(n_intermediate_steps)
         if action_penalty is not None:

@@ -604,6 +604,31 @@ def test_free_running_constraint_statistics_against_oracle():
     assert d_dq <= 1e-4 and o_dq <= 1e-9
 
 
+@pytest.mark.parametrize('dt', ['f64', 'f32'])
+def test_circle_time_step_quirk_through_capi(golden, dt):
+    """Quirk Q4 (G4b): `time_step` of CircleEnvAtacom / CircleEnvErrorCorrection reaches only the wrapper -- the reference's
+    own trajectories at time_step 0.02 / 0.004 through the HIP path (the facades pass time_step exactly as the reference
+    constructors do)."""
+    g = golden('circle_time_step')
+    for tag, name in (('A', 'circle'), ('A2', 'circle'), ('E', 'circle_ec')):
+        ts = float(g[tag + '_time_step'])
+        acts, obs, ss = g[tag + '_actions'], g[tag + '_obs'], g[tag + '_s']
+        n, T, _ = acts.shape
+        env = _env(name, n, dt, time_step=ts, horizon=T)
+        full = env.get_state().cpu().numpy().astype(np.float64)
+        assert np.allclose(full[:, 4:5], g[tag + '_s0'], atol=1e-6)
+        worst = 0.0
+        for t in range(T):
+            if t > 0:
+                full[:, :4], full[:, 4:5], full[:, -1] = obs[:, t - 1], ss[:, t - 1], t
+                env.set_state(full)
+            o, r, ab, _ = env.step(acts[:, t])
+            s_dev = env.get_state().cpu().numpy()[:, 4:5]
+            worst = max(worst, np.abs(o.cpu().numpy() - obs[:, t]).max(), np.abs(s_dev - ss[:, t]).max(),
+                        np.abs(r.cpu().numpy() - g[tag + '_reward'][:, t]).max())
+        assert worst < (1e-9 if dt == 'f64' else 5e-4), (tag, worst)
+
+
 def test_reference_facade_surface(golden):
     """Drop-in surface: constructor names / arguments, info, reset / step return types (atacom.py:93-115)."""
     from rl_on_manifold_amd import CircleEnvAtacom, AirHockeyIiwaAtacom, AirHockeyPlanarAtacom

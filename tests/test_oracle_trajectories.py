@@ -109,3 +109,23 @@ def test_generic_wrapper_constraint_logs(golden, name):
     c_avg, c_max, c_dq = env.get_constraints_logs()
     assert c_max < max(1.5 * logs[:, 1].max(), logs[:, 1].max() + 0.02)
     assert c_dq <= 1e-6
+
+
+def test_circle_time_step_reaches_only_the_wrapper(golden):
+    """Quirk Q4 (golden set G4b): CircleEnvAtacom / CircleEnvErrorCorrection hand `time_step` to the wrapper (slack
+    integration, atacom.py:135) but build the base CircularMotion without it, so the point mass keeps integrating at
+    0.01 (circle_atacom.py:7-18).  The reference's trajectories at time_step 0.02 / 0.004, replayed teacher-forced."""
+    from oracle import atacom_batched as ob
+    g = golden('circle_time_step')
+    for tag, specf in (('A', osc.circle_spec), ('A2', osc.circle_spec), ('E', osc.circle_ec_spec)):
+        ts = float(g[tag + '_time_step'])
+        acts = g[tag + '_actions']
+        n, T, _ = acts.shape
+        env = ob.BatchedAtacomEnv(specf(horizon=T, dt=ts), n)
+        assert np.allclose(env.s, g[tag + '_s0'], atol=1e-14)
+        for t in range(T):
+            if t > 0:
+                env.q[:], env.dq[:], env.s[:] = g[tag + '_obs'][:, t - 1, :2], g[tag + '_obs'][:, t - 1, 2:], g[tag + '_s'][:, t - 1]
+            o, r, ab, _ = env.step(acts[:, t])
+            assert np.abs(o - g[tag + '_obs'][:, t]).max() < 1e-12 and np.abs(env.s - g[tag + '_s'][:, t]).max() < 1e-12
+            assert np.abs(r - g[tag + '_reward'][:, t]).max() < 1e-12
