@@ -103,6 +103,8 @@ def feasible_init(name, B, dev, gen, sigma=0.05):
                       device=dev, dtype=torch.float32)
     keep, drawn = [], 0
     while sum(k.shape[0] for k in keep) < B:
+        if drawn > 200 * B:
+            raise RuntimeError('feasible_init: fewer than 0.5 %% of the draws are feasible (%s)' % name)
         n = max(B // 2, 1024)
         q = q0 + sigma * torch.randn((n, nq), device=dev, generator=gen)
         dq = torch.zeros_like(q)

@@ -165,7 +165,8 @@ class VectorizedAtacomEnv:
 
     Environments whose mask entry is False keep their state (a vector Core masks out the environments that have already
     delivered their episodes); the engine steps the whole batch in one launch, so a partial mask costs a state
-    save / restore around the launch."""
+    save / restore around the launch -- and the constraint statistics (`get_constraints_logs`) keep counting the
+    masked-out environments' discarded steps, so read them from full-mask phases."""
 
     def __init__(self, env, n_envs, device='cuda:0', dtype=torch.float32, **engine_kwargs):
         self._engine = BatchedAtacomEnv(env, n_envs, device=device, dtype=dtype, **engine_kwargs)

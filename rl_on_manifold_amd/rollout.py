@@ -108,7 +108,9 @@ class RolloutCollector:
     # ------------------------------------------------------------------ the one collective
     def gather(self, buf, out=None):
         """All-gather the packed rollout: [T, Bm, F] on every rank -> [W, T, Bm, F] on every rank, rank r's shard in
-        block r (its first sizes[r] env rows are valid).  One collective, written straight into the final buffer."""
+        block r (its first sizes[r] env rows are valid).  One collective, written straight into the final buffer.
+        Without `out` the result lives in a buffer the collector keeps and REUSES: the next gather overwrites it (an
+        on-policy learner consumes a dataset before collecting the next one); pass `out` or clone to keep it."""
         if self.world == 1:
             return buf.unsqueeze(0)
         T, Bm, F = buf.shape
