@@ -301,6 +301,24 @@ def main():
         t2 = time.perf_counter()
         t_roll.append(t1 - t0)
         t_gath.append(t2 - t1)
+    # the same two collections with the first all-gather left in flight while the second rollout runs (collect_async)
+    t_pipe = None
+    if world > 1:
+        rec2 = torch.empty_like(rec)
+        out_a = torch.empty((world,) + tuple(rec.shape), device=dev, dtype=rec.dtype)
+        t_pipe = []
+        for _ in range(3):
+            sync_all()
+            t0 = time.perf_counter()
+            env.rollout_packed(actions=racts, out=rec)
+            _, work = col.gather(rec, out=out_a, async_op=True)
+            env.rollout_packed(actions=racts, out=rec2)
+            work.wait()
+            g2 = col.gather(rec2)
+            torch.cuda.synchronize(dev)
+            t_pipe.append(time.perf_counter() - t0)
+        t_pipe = float(np.median(max_over_ranks(t_pipe)))
+        del rec2, out_a, g2
     t_roll = float(np.median(max_over_ranks(t_roll)))
     t_gath = float(np.median(max_over_ranks(t_gath)))
     sent = rec.numel() * rec.element_size()
@@ -311,6 +329,7 @@ def main():
                   'bytes_sent_per_rank': sent, 'bytes_received_per_rank': recv if world > 1 else 0,
                   'allgather_GBps_per_rank': (recv - sent) / t_gath / 1e9 if world > 1 else None,
                   'collection_env_steps_per_s': world * B * T / (t_roll + (t_gath if world > 1 else 0.0)),
+                  'two_collections_overlapped_ms': t_pipe * 1e3 if t_pipe else None,
                   'backend': backend if world > 1 else None}
     del gathered
 

@@ -106,13 +106,15 @@ class RolloutCollector:
         return buf
 
     # ------------------------------------------------------------------ the one collective
-    def gather(self, buf, out=None):
+    def gather(self, buf, out=None, async_op=False):
         """All-gather the packed rollout: [T, Bm, F] on every rank -> [W, T, Bm, F] on every rank, rank r's shard in
         block r (its first sizes[r] env rows are valid).  One collective, written straight into the final buffer.
         Without `out` the result lives in a buffer the collector keeps and REUSES: the next gather overwrites it (an
-        on-policy learner consumes a dataset before collecting the next one); pass `out` or clone to keep it."""
+        on-policy learner consumes a dataset before collecting the next one); pass `out` or clone to keep it.
+        async_op=True returns (result, work): the collective runs on the backend's own stream (RCCL) while the caller
+        goes on -- e.g. launches the next rollout -- and `work.wait()` orders the result before its first use."""
         if self.world == 1:
-            return buf.unsqueeze(0)
+            return (buf.unsqueeze(0), _Done()) if async_op else buf.unsqueeze(0)
         T, Bm, F = buf.shape
         shape = (self.world, T, Bm, F)
         if buf.is_cuda and dist.get_backend(self.group) == 'gloo':
@@ -120,15 +122,15 @@ class RolloutCollector:
             # BENCH_DIST_BACKEND=gloo).  The production transport is RCCL, device to device, below.
             host = torch.empty(shape, dtype=buf.dtype)
             dist.all_gather_into_tensor(host.view(self.world * T, Bm, F), buf.cpu(), group=self.group)
-            return host.to(buf.device)
+            return (host.to(buf.device), _Done()) if async_op else host.to(buf.device)
         if out is None:
             if self._recv is None or tuple(self._recv.shape) != shape or self._recv.dtype != buf.dtype \
                     or self._recv.device != buf.device:
                 self._recv = torch.empty(shape, device=buf.device, dtype=buf.dtype)
             out = self._recv
         # output handed over as the concatenation along dim 0 (the form every backend accepts)
-        dist.all_gather_into_tensor(out.view(self.world * T, Bm, F), buf, group=self.group)
-        return out
+        work = dist.all_gather_into_tensor(out.view(self.world * T, Bm, F), buf, group=self.group, async_op=async_op)
+        return (out, work) if async_op else out
 
     def unpack(self, g):
         """Views (no copy) into gathered records [W, T, Bm, F]: every entry is [W, T, Bm, ...]."""
@@ -150,6 +152,15 @@ class RolloutCollector:
         """Local rollout + global all-gather.  Returns the unpacked global dataset, shard-major [W, T, Bm, ...]."""
         return self.unpack(self.gather(self.collect_local(n_steps, actions=actions, policy=policy, noise=noise)))
 
+    def collect_async(self, n_steps, actions=None, policy=None, noise=None, out=None):
+        """Like collect(), but the all-gather is left in flight: returns a PendingRollout whose .wait() gives the
+        dataset.  Lets a learner overlap the collective (1.4 GB received per rank for config 5) with whatever it does
+        next on the compute stream -- typically the first kernels of its update, or the next rollout into another
+        buffer (pass a distinct `out` per buffer in flight)."""
+        local = self.collect_local(n_steps, actions=actions, policy=policy, noise=noise)
+        g, work = self.gather(local, out=out, async_op=True)
+        return PendingRollout(self, g, work, local)
+
     # ------------------------------------------------------------------ constraint statistics
     def get_constraints_logs(self, n_logged):
         """Global (c_avg, c_max, c_dq_max): the reference's get_constraints_logs (atacom.py:207-216) over every env
@@ -165,6 +176,23 @@ class RolloutCollector:
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
         dist.all_reduce(sm, op=dist.ReduceOp.SUM, group=self.group)
         return float(sm[0] / sm[1]), float(mx[0]), float(mx[1])
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+class PendingRollout:
+    """A collection whose all-gather may still be running (RolloutCollector.collect_async)."""
+
+    def __init__(self, collector, gathered, work, local):
+        self._c, self._g, self._work, self._local = collector, gathered, work, local     # `local` is the send buffer:
+                                                                                           # kept alive until the wait
+    def wait(self):
+        self._work.wait()
+        self._local = None
+        return self._c.unpack(self._g)
 
 
 def to_mushroom_dataset(data):

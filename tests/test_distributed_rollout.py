@@ -41,6 +41,11 @@ def _worker(rank, world, port, q):
         sm = col.collect(T, actions=_actions()[:, lo:hi])             # shard-major views [W, T, Bm, ...]
         assert sm['obs'].shape[:3] == (world, T, max(col.sizes))
         data = col.time_major(sm)
+        # the same collection with the all-gather left in flight gives the same dataset
+        eng2 = OracleEngine(NAME, hi - lo, init_q=_init_q()[lo:hi], horizon=5)
+        pend = RolloutCollector(eng2, global_batch=GLOBAL_B).collect_async(T, actions=_actions()[:, lo:hi])
+        again = pend.wait()
+        assert all(torch.equal(again[k_], sm[k_]) for k_ in sm)
         stats = col.get_constraints_logs(n_logged=T * (hi - lo))
         q.put((rank, {k: v.numpy() for k, v in data.items()}, stats))
         dist.barrier()
