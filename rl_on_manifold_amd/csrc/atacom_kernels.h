@@ -20,7 +20,10 @@ namespace atacom {
 constexpr int WAVE = 64;
 // threads per workgroup of the step / rollout kernels: the quad mapping runs 2.7 % faster with four waves per
 // workgroup (one per SIMD of a CU, sharing the instruction cache), the lane mapping with one (measured, profiles/)
-template <int LANES> constexpr int BLOCK = (LANES > 1) ? 256 : 64;
+#ifndef ATACOM_BLOCK_GROUP
+#define ATACOM_BLOCK_GROUP 256
+#endif
+template <int LANES> constexpr int BLOCK = (LANES > 1) ? ATACOM_BLOCK_GROUP : 64;
 
 // ------------------------------------------------------------------ plane layout of the state buffer
 template <typename E>
