@@ -62,8 +62,8 @@ typedef struct atacom_config {
                             (what mushroom_rl.Core does between steps); the returned obs is still the
                             terminal observation, the next call starts from the reset state */
     int32_t lanes_per_env; /* kernel mapping: 1 = one env per lane, 2 = one env per lane pair, 4 = one env per DPP
-                              quad (null-space solve split by column over the 2 / 4 lanes), 0 = let the library
-                              choose per env / batch.
+                              quad, 8 = one env per 8 lanes (null-space solve split by column over the 2 / 4 / 8
+                              lanes), 0 = let the library choose per env / batch (it never chooses 8).
                               Results are the same algorithm either way (summation order differs). */
     double dt;           /* time_step */
     double rref_tol;     /* 0.05, atacom.py:128 */
@@ -211,7 +211,7 @@ int atacom_forward_dynamics(int32_t dtype, int32_t n, const void* d_q, const voi
  *   atacom_constraint_terms: q, dq [n, dim_q] -> fun [n, c], J [n, c, dim_q], b [n, c]: the fun / J / b
  *     callables handed to ViabilityConstraint (circle_atacom.py:47-70, atacom_air_hockey.py:78-107,
  *     iiwa_hit_atacom.py:70-139).  cfg supplies geometry and bias_mode. */
-int atacom_nullspace(int32_t env_id, int32_t dtype, int32_t lanes_per_env /* 1, 2 or 4 */, int32_t n, const void* d_Jc,
+int atacom_nullspace(int32_t env_id, int32_t dtype, int32_t lanes_per_env /* 1, 2, 4 or 8 */, int32_t n, const void* d_Jc,
                      const void* d_rhs, double tol, void* d_x, void* d_null, void* d_rref, void* stream);
 int atacom_constraint_terms(const atacom_config* cfg, int32_t n, const void* d_q, const void* d_dq, void* d_fun,
                             void* d_J, void* d_b, void* stream);

@@ -10,7 +10,7 @@ namespace atacom {
 struct EnvOps {
     int n_planes, n_iplanes, state_dim, init_dim, obs_dim, nq, nf, ng, nk;
     size_t elem;
-    // lanes = 1 or 4 (lanes per environment)
+    // lanes = 1, 2, 4 or 8 (lanes per environment)
     void (*step)(const atacom_config&, int lanes, void* f, int* ip, const void* act, void* obs, void* rew,
                  uint8_t* ab, uint8_t* last, hipStream_t s);
     void (*rollout)(const atacom_config&, int lanes, int n_steps, void* f, int* ip, const void* acts, void* obs,

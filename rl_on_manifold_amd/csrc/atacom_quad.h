@@ -1,21 +1,21 @@
-// Lane-group variant of the null-space solver: FOUR (a DPP quad) or TWO (a lane pair) LANES PER ENVIRONMENT.
+// Lane-group variant of the null-space solver: EIGHT, FOUR (a DPP quad) or TWO (a lane pair) LANES PER ENVIRONMENT.
 // (Written and described for the quad; the group size is the template parameter LN, see qbcast / qsum below.)
 //
 // Why (measured in profiles/): a wave64 vector instruction occupies its SIMD for 4 clocks and a
 // lone wave already saturates it, so the step time is (vector instructions per wave) x ~5 clk.  With one environment
-// per lane the headline batch of 8192 environments is 128 wavefronts on 1024 SIMDs, each running the whole 24 k-
-// instruction step (52 us).  Splitting every environment over the 4 lanes of a DPP quad puts 512 waves to work at
-// ~0.6x the instructions per wave (30 us); beyond 16384 environments (1024 waves) the lane mapping wins again
-// because its total instruction count is lower.
+// per lane the headline batch of 8192 environments is 128 wavefronts on 1024 SIMDs, each running the whole 23 k-
+// instruction step (53 us).  Splitting every environment over the 4 lanes of a DPP quad puts 512 waves to work at
+// ~0.55x the instructions per wave (28 us); beyond 16384 environments (1024 waves) the narrower mappings win again
+// because their total instruction count is lower.
 //
-// Data distribution inside a quad (lq = lane & 3):
-//   * matrices with N columns (J_c: M x N, null basis: N x K) are split BY COLUMN: column c lives in lane
-//     c % 4, "slot" c / 4  (S = ceil(N / 4) slots per lane; slots past N hold zeros);
+// Data distribution inside a quad (lq = lane & 3) -- "column 0 replicated", see split_slots below:
+//   * matrices with N columns (J_c: M x N, null basis: N x K): column 0 is held by every lane, column c >= 1 lives in
+//     lane (c - 1) % 4, "slot" (c - 1) / 4  (S = ceil((N - 1) / 4) slots per lane; slots past N hold zeros);
 //   * vectors over the M rows (rhs y, the bidiagonal d / e, left reflectors u) are REPLICATED in the four
 //     lanes and computed redundantly -- their values stay bitwise identical across the quad because every
 //     cross-lane sum uses the same commutative butterfly;
-//   * cross-lane traffic is DPP only (quad_perm): a broadcast is one v_mov_dpp, a quad sum two v_add_f32_dpp;
-//     no LDS, no ds_bpermute, no barriers;
+//   * cross-lane traffic is DPP only (quad_perm; row_half_mirror for 8 lanes): a broadcast is one v_mov_dpp, a quad
+//     sum two v_add_f32_dpp; no LDS, no ds_bpermute, no barriers;
 //   * "my column of a replicated array" is picked by a one-hot FMA blend, never by a select chain on lq (the
 //     optimiser turns those into a divergent 4-way switch).
 // The arithmetic is the same Householder bidiagonalisation / rref chart as atacom_linalg.h (the one-lane-per-env

@@ -43,6 +43,7 @@ for name, spec in (('planar', osc.planar_spec()), ('iiwa', osc.iiwa_spec())):
         if last.any():
             o.reset(last)
     E, M, C = np.array(E).ravel(), np.array(M).ravel(), np.array(C).ravel()
+    os.makedirs(os.path.join(os.path.dirname(HERE), 'gpurun_out'), exist_ok=True)
     np.savez_compressed(os.path.join(os.path.dirname(HERE), 'gpurun_out', 'r02_margin_%s_l%d.npz' % (name, lanes)), E=E, M=M, C=C,
                         K=np.array(K).ravel(), EC=np.array(EC).reshape(-1, 5), SM=np.array(SM).ravel())
     print('== %s lanes %d: %d env-steps, median err %.2e, p99 %.2e, p99.9 %.2e, max %.2e'
