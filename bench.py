@@ -228,6 +228,10 @@ def main():
         sys.exit('bench.py: --gpus %d contradicts WORLD_SIZE=%d of the launcher' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        # before the HIP / HSA runtime comes up (first torch.cuda call): the host driver only supports dmabuf IPC
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
 
     import numpy as np
     import torch
@@ -247,8 +251,6 @@ def main():
     dev = torch.device('cuda', local_rank % n_dev)
     torch.cuda.set_device(dev)
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         kw = {'device_id': dev} if backend == 'nccl' else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     red_dev = dev if backend == 'nccl' else torch.device('cpu')
