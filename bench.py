@@ -194,6 +194,28 @@ def time_steps(env, actions, K, W, min_time, sync_all, max_over_ranks, max_block
     return secs, kern_ms
 
 
+def graphed_step_us(env, actions, n=20, reps=30):
+    """The same step launches replayed from ONE HIP graph (rl_on_manifold_amd.GraphedRollout: observe -> policy -> step,
+    n times; here the "policy" hands out the pre-generated actions): what the launch path costs on top of the kernels."""
+    import torch
+    from rl_on_manifold_amd import GraphedRollout
+    it = [0]
+
+    def policy(obs):
+        a = actions[it[0] % actions.shape[0]]
+        it[0] += 1
+        return a
+
+    loop = GraphedRollout(env, policy, n)
+    loop.replay()
+    torch.cuda.synchronize(env.device)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        loop.replay()
+    torch.cuda.synchronize(env.device)
+    return (time.perf_counter() - t0) / (reps * n) * 1e6
+
+
 def roofline_objects(name, B, kern_ms, traffic=None):
     algo_bytes = ALGO_BYTES[name] * B
     flops = algorithmic_flops(name) * B
@@ -416,10 +438,12 @@ def secondary_records(dev, gen, K, W, sync_all, max_over_ranks):
             env.rollout_packed(actions=racts, out=rec)
         torch.cuda.synchronize(dev)
         roll = 5 * 120 * B / (time.perf_counter() - t0)
+        g_us = graphed_step_us(env, acts)
         roof, roof_valu = roofline_objects(name, B, kern_ms)
         out.append({'workload': WORKLOAD[name] + ', batch %d' % B, 'value': B * K / el, 'unit': 'env-steps/s',
                     'ms_per_step': el / K * 1e3, 'blocks': len(secs), 'max_abs_c': c_max, 'c_avg': c_avg,
-                    'c_dq_max': c_dq, 'rollout_kernel_env_steps_per_s': roll, 'roofline': roof,
+                    'c_dq_max': c_dq, 'rollout_kernel_env_steps_per_s': roll,
+                    'hip_graph_20_steps_us_per_step': g_us, 'roofline': roof,
                     'roofline_valu': roof_valu})
         env.close()
     return out

@@ -271,6 +271,67 @@ class BatchedAtacomEnv:
             pass
 
 
+class GraphedRollout:
+    """A T-step collection loop -- observe, ARBITRARY torch policy, env step -- captured ONCE in a HIP graph and replayed
+    with one host call per collection phase.
+
+    The fused `rollout_policy` kernel covers the reference's actor MLPs; this covers everything else a caller may put
+    between observation and action (recurrent nets, ensembles, torch-side preprocessing) without a tracing compiler and
+    without per-step Python: the C-ABI entry points only enqueue kernels on the caller's stream, so they are capturable
+    as they are.  What it buys depends on how launch-bound the step is (measured, 20-step graphs, MI355X): circle
+    7.6 -> 2.7 us per step, planar 11.2 -> 10.7, iiwa 27.8 -> 27.5.
+
+      loop = GraphedRollout(env, policy, n_steps=120)      # policy: obs [B, D] -> actions [B, k], torch ops on env.device
+      data = loop.replay()                                  # dict of static tensors: obs, action, reward, next_obs, absorbing, last
+
+    The returned tensors are the graph's static buffers (overwritten by the next replay).  `policy` must be capturable:
+    no host synchronisation, no data-dependent Python control flow."""
+
+    def __init__(self, env, policy, n_steps, warmup=2):
+        self.env, self.T = env, int(n_steps)
+        T, B, D, k = self.T, env.batch, env.obs_dim, env.dims['null']
+        dev, dt = env.device, env.dtype
+        self.out = {'obs': torch.empty((T, B, D), device=dev, dtype=dt),
+                    'action': torch.empty((T, B, k), device=dev, dtype=dt),
+                    'reward': torch.empty((T, B), device=dev, dtype=dt),
+                    'next_obs': torch.empty((T, B, D), device=dev, dtype=dt),
+                    'absorbing': torch.empty((T, B), device=dev, dtype=torch.uint8),
+                    'last': torch.empty((T, B), device=dev, dtype=torch.uint8)}
+        self._none = torch.zeros((B,), device=dev, dtype=torch.uint8)       # reset mask selecting nobody = "observe"
+        saved = env.get_state().clone()
+        aux = env.get_aux_state().clone() if env.env_id == _lib.ENV_IIWA else None
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                                       # warm-up outside the capture (lazy inits)
+            for _ in range(warmup):
+                self._body(policy, min(T, 2))
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self._restore(saved, aux)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._body(policy, T)
+        self._restore(saved, aux)                                           # the capture itself does not run the kernels,
+                                                                            # but the warm-up did
+
+    def _restore(self, saved, aux):
+        self.env.set_state(saved)
+        if aux is not None:
+            self.env.set_aux_state(aux)
+
+    def _body(self, policy, n):
+        env, o = self.env, self.out
+        for t in range(n):
+            # observation of the CURRENT state (after an auto-reset it differs from the previous step's terminal obs)
+            _lib.check(env._lib.atacom_reset(env._h, _ptr(self._none), None, _ptr(o['obs'][t]), env._stream()))
+            o['action'][t].copy_(policy(o['obs'][t]))
+            _lib.check(env._lib.atacom_step(env._h, _ptr(o['action'][t]), _ptr(o['next_obs'][t]), _ptr(o['reward'][t]),
+                                            _ptr(o['absorbing'][t]), _ptr(o['last'][t]), env._stream()))
+
+    def replay(self):
+        self.graph.replay()
+        return self.out
+
+
 class MlpPolicy:
     """Weights of a reference-style actor network for BatchedAtacomEnv.rollout_policy.
 

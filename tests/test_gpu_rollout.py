@@ -231,3 +231,35 @@ def test_vectorized_env_core_shaped_loop():
     assert (np.abs(q) <= hi[6:12] + 1e-6).all()                     # ATACOM keeps the joints inside the bounds it advertises
     c_avg, c_max, c_dq = env.get_constraints_logs()
     assert np.isfinite([c_avg, c_max, c_dq]).all() and c_max < 0.05
+
+
+@pytest.mark.parametrize('name', ['circle', 'iiwa'])
+def test_graphed_rollout_equals_the_rollout_kernel(name):
+    """GraphedRollout: observe -> torch policy -> atacom_step, T times, captured in one HIP graph.  With a deterministic
+    policy that depends on the observation it must reproduce `rollout()` fed with the actions it chose (auto-reset
+    included), replay after replay."""
+    from rl_on_manifold_amd import GraphedRollout
+    B, T = 300, 14
+    env = _env(name, B, horizon=6)
+    k, D = env.dims['null'], env.obs_dim
+    g = torch.Generator(device=DEV).manual_seed(7)
+    W = torch.randn((D, k), device=DEV, generator=g) * 0.5
+
+    def policy(obs):                       # any capturable torch code
+        return torch.tanh(obs @ W) * 1.2
+
+    st = env.get_state().clone()
+    loop = GraphedRollout(env, policy, T)
+    assert torch.equal(env.get_state(), st)                        # building the graph leaves the engine where it was
+    for rep in range(2):
+        env.set_state(st)
+        data = loop.replay()
+        torch.cuda.synchronize()
+        acts = data['action'].clone()
+        env.set_state(st)
+        ref = env.rollout(acts)
+        for key in ('obs', 'next_obs', 'reward'):
+            assert torch.equal(data[key], ref[key]), (rep, key)
+        assert torch.equal(data['last'], ref['last']) and torch.equal(data['absorbing'], ref['absorbing'])
+        assert torch.allclose(acts, torch.tanh(data['obs'] @ W) * 1.2, atol=1e-6)
+        assert data['last'][5].all()                               # horizon 6, auto-reset inside the graph
