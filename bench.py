@@ -446,6 +446,32 @@ def secondary_records(dev, gen, K, W, sync_all, max_over_ranks):
                     'hip_graph_20_steps_us_per_step': g_us, 'roofline': roof,
                     'roofline_valu': roof_valu})
         env.close()
+    # the iiwa headline workload through the allocating Python surface (step(): clones + bool conversion per call), and
+    # in the opt-in rigid-body mode (row N4)
+    import rl_on_manifold_amd as pkg
+    for label, kw in (('python step() surface', {}), ('rigid-body mode (dynamics_mode = 1)', {'dynamics_mode': 'rigid_body'})):
+        B = 8192
+        env = pkg.BatchedAtacomEnv('iiwa', B, device=dev, dtype=torch.float32, auto_reset=True, **kw)
+        init, _ = feasible_init('iiwa', B, dev, gen)
+        env.reset(state=init)
+        acts = torch.rand((64, B, 5), device=dev, generator=gen) * 2 - 1
+        if kw:
+            secs, kern_ms = time_steps(env, acts, K, W, 0.2, sync_all, max_over_ranks)
+            el = float(np.median(secs))
+        else:
+            for i in range(W):
+                env.step(acts[i % 64])
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            n = max(K, 200)
+            for i in range(n):
+                env.step(acts[i % 64])
+            torch.cuda.synchronize(dev)
+            el = (time.perf_counter() - t0) * K / n
+        c_avg, c_max, c_dq = env.get_constraints_logs()
+        out.append({'workload': 'IiwaAirHockey env 7H, batch 8192, ' + label, 'value': B * K / el, 'unit': 'env-steps/s',
+                    'ms_per_step': el / K * 1e3, 'max_abs_c': c_max, 'c_avg': c_avg, 'c_dq_max': c_dq})
+        env.close()
     return out
 
 
