@@ -151,14 +151,22 @@ class BatchedAtacomEnv:
         their stored initial state first.  Returns the observation of every env."""
         m = None if mask is None else self._as_dev(mask, (self.batch,), torch.uint8)
         s = None if state is None else self._as_dev(state, (self.batch, self.init_state_dim))
-        _lib.check(self._lib.atacom_reset(self._h, _ptr(m), _ptr(s), _ptr(self._obs), self._stream()))
-        return self._obs.clone()
+        obs = torch.empty((self.batch, self.obs_dim), device=self.device, dtype=self.dtype)     # fresh: the caller keeps it
+        _lib.check(self._lib.atacom_reset(self._h, _ptr(m), _ptr(s), _ptr(obs), self._stream()))
+        return obs
 
     def step(self, actions):
         a = self._as_dev(actions, (self.batch, self.dims['null']))
-        _lib.check(self._lib.atacom_step(self._h, _ptr(a), _ptr(self._obs), _ptr(self._reward),
-                                          _ptr(self._absorbing), _ptr(self._last), self._stream()))
-        return self._obs.clone(), self._reward.clone(), self._absorbing.bool(), {'last': self._last.bool()}
+        # fresh output tensors written by the kernel itself (the reference returns copies, atacom.py:115); the flags are
+        # 0 / 1 bytes, so the bool tensors are reinterpreting views -- no copy or conversion kernel follows the step
+        B = self.batch
+        obs = torch.empty((B, self.obs_dim), device=self.device, dtype=self.dtype)
+        reward = torch.empty((B,), device=self.device, dtype=self.dtype)
+        absorbing = torch.empty((B,), device=self.device, dtype=torch.uint8)
+        last = torch.empty((B,), device=self.device, dtype=torch.uint8)
+        _lib.check(self._lib.atacom_step(self._h, _ptr(a), _ptr(obs), _ptr(reward), _ptr(absorbing), _ptr(last),
+                                          self._stream()))
+        return obs, reward, absorbing.view(torch.bool), {'last': last.view(torch.bool)}
 
     def step_into(self, actions, obs, reward, absorbing, last=None):
         """Allocation-free variant of step(): caller-owned output tensors (uint8 for the flags)."""
