@@ -45,8 +45,10 @@ class _Facade:
         """atacom.py:106-115: returns (state copy, float reward, bool absorbing, {})."""
         a = np.asarray(action, dtype=np.float64).reshape(1, -1)
         obs, r, ab, _ = self._engine.step(a)
-        self.state = obs[0].cpu().numpy().astype(np.float64)
-        return self.state.copy(), float(r[0].item()), bool(ab[0].item()), {}
+        # one device -> host transfer (and one synchronisation) per step: observation, reward and flag travel together
+        host = torch.cat([obs[0], r, ab.to(obs.dtype)]).cpu().numpy().astype(np.float64)
+        self.state = host[:-2].copy()
+        return self.state.copy(), float(host[-2]), bool(host[-1] != 0.0), {}
 
     def get_constraints_logs(self):
         return self._engine.get_constraints_logs()
