@@ -95,3 +95,33 @@ def test_observation_bounds_follow_the_reference(lib_built, golden):
     assert lo.shape == (12,) and np.isfinite(hi[[0, 1, 2, 6, 7, 8, 9, 10, 11]]).all()
     lo, hi = BatchedAtacomEnv.observation_bounds(_lib.ENV_CIRCLE, _lib.default_config(_lib.ENV_CIRCLE))
     assert np.all(np.isinf(lo)) and lo.shape == (4,)                                   # circle_base.py:21-22
+
+
+def _build_c_consumer(lib_built, tmp_path):
+    import subprocess
+    exe = str(tmp_path / 'capi_demo')
+    libdir = os.path.dirname(lib_built)
+    cmd = ['gcc', '-std=c11', '-Wall', '-Werror', '-O2', '-D__HIP_PLATFORM_AMD__', os.path.join(ROOT, 'examples', 'capi_demo.c'),
+           '-I' + os.path.join(ROOT, 'include'), '-I/opt/rocm/include', '-L' + libdir, '-latacom_hip', '-L/opt/rocm/lib',
+           '-lamdhip64', '-lm', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib', '-o', exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_program_links(lib_built, tmp_path):
+    """The boundary is a C ABI: include/atacom_hip.h compiles as C11 with -Wall -Werror and a plain-C consumer
+    (examples/capi_demo.c: no Python, no torch) links against the library."""
+    assert os.path.exists(_build_c_consumer(lib_built, tmp_path))
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_plain_c_consumer_runs(lib_built, tmp_path):
+    import subprocess
+    exe = _build_c_consumer(lib_built, tmp_path)
+    r = subprocess.run([exe, '2048', '120'], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert 'c_max' in r.stdout
