@@ -134,16 +134,6 @@ template <> struct tiny_of<float> { static constexpr float value = 1e-30f; };
 template <> struct tiny_of<double> { static constexpr double value = 1e-280; };
 template <typename T>
 __device__ __forceinline__ T larfg_scale(T alpha, T ss, T& beta, T& tau) {
-#ifdef ATACOM_LARFG_GUARDED        // A/B switch: dlarfg's special cases as five selects (the round-1 form)
-    const bool nz = ss != T(0);
-    const T nrm0 = num<T>::sqrt(num<T>::fma(alpha, alpha, ss));
-    const T b0 = -num<T>::copysign(nrm0, alpha);
-    beta = nz ? b0 : alpha;
-    const T safe_b = nz ? b0 : T(1);
-    tau = nz ? num<T>::div(b0 - alpha, safe_b) : T(0);
-    const T den = nz ? (alpha - b0) : T(1);
-    return nz ? num<T>::rcp(den) : T(0);
-#endif
     const T nrm = num<T>::sqrt(num<T>::fma(alpha, alpha, ss));
     const T b = num<T>::copysign(num<T>::max(nrm, tiny_of<T>::value), -alpha);   // = -sign(alpha) max(nrm, TINY)
     const T dm = b - alpha;                                                       // |dm| = |b| + |alpha| >= TINY
