@@ -296,6 +296,10 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
     T m0x = T(0), m0y = T(0);   // mallet position at the start of the env step
     T A[NC][NQ], yb[NC];       // yb = psi + Kc c0: the slack-independent part of the right-hand side (one value
                                // per row carried over the sub-steps instead of two)
+    // hoist of the sub-step-invariant first reflector (see prepare): group mappings, ATACOM mode, held q / dq, and an
+    // equality row on top of J_c (iiwa; the planar and circle J_c start with a slack-carrying row)
+    constexpr bool G0PRE = HOLD && LANES > 1 && E::MODE == 0 && NF > 0 && NQ > 1;
+    T g0_d = T(0), g0_tau = T(0);
     constexpr int LGC = LANES > 1 ? LANES : 4;                  // lanes per environment of the group solver
     constexpr int SQ = split_slots(NN, LGC);
     T Aq[NC][SQ];              // LANES > 1: this lane's columns of [K J | 0] (column c >= 1 -> lane (c-1) % LANES,
@@ -326,6 +330,30 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 const T psi = num<T>::fma(P.K[r], bst[r], jdq);      // constraints.py:42-43
                 const T c0 = num<T>::fma(P.K[r], jdq, fun[r]);       // constraints.py:33-37
                 yb[r] = (E::MODE == 1) ? P.Kc[r] * c0 : num<T>::fma(P.Kc[r], c0, psi);   // E: no drift term (:127)
+            }
+            if constexpr (G0PRE) {
+                // G(0), the first right reflector of the bidiagonalisation, only sees row 0 = [K_f J_f | 0] (an equality row
+                // carries no slack) and only mixes the dim_q joint columns; q, dq -- hence K J -- are held over the
+                // sub-steps (HOLD), so it is generated and applied ONCE per step here instead of once per sub-step in the
+                // solver (which receives row 0 = the reflector vector and the updated rows below, PRE0).
+                T ss = T(0);
+#pragma unroll
+                for (int c = 1; c < NQ; ++c) ss = num<T>::fma(A[0][c], A[0][c], ss);
+                T beta;
+                const T sc = larfg_scale(A[0][0], ss, beta, g0_tau);
+                g0_d = beta;
+#pragma unroll
+                for (int c = 1; c < NQ; ++c) A[0][c] *= sc;
+#pragma unroll
+                for (int r = 1; r < NC; ++r) {
+                    T w = A[r][0];
+#pragma unroll
+                    for (int c = 1; c < NQ; ++c) w = num<T>::fma(A[r][c], A[0][c], w);
+                    w *= g0_tau;
+                    A[r][0] -= w;
+#pragma unroll
+                    for (int c = 1; c < NQ; ++c) A[r][c] = num<T>::fma(-w, A[0][c], A[r][c]);
+                }
             }
             ATACOM_MARK("PRE_blend");
             if (LANES > 1) {
@@ -410,7 +438,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
             };
             auto a0get = [&](auto rc) -> T { return A[decltype(rc)::value][0]; };      // NQ >= 1: never a slack column
             auto yget = [&](auto rc) -> T { return y[decltype(rc)::value]; };
-            bidiag_solve_null_quad<T, NC, NN, LG>(aget, a0get, yget, x0, x, nb0, nb, lq);
+            bidiag_solve_null_quad<T, NC, NN, LG, G0PRE>(aget, a0get, yget, x0, x, nb0, nb, lq, g0_d, g0_tau);
             rref_apply_quad<T, NN, ND, LG>(nb0, nb, alphaq, P.rref_tol, nmu0, nmu, lq);
             ATACOM_MARK("MU_gather");
             mu[0] = nmu0 - x0;

@@ -251,10 +251,15 @@ __host__ __device__ constexpr int split_slots(int n, int ln) { return (n - 1 + l
 // (std::integral_constant), so the operands are born in their register pairs: an intermediate T a[M][S] array here
 // made the optimiser merge neighbouring stores and then fail to dissolve the array, which put it in scratch / LDS
 // (+10 us per step, measured).
-template <typename T, int M, int N, int LN, typename AF, typename A0F, typename YF>
+// PRE0: the first right reflector G(0) has been generated and applied by the caller (it is the same for the four
+// physics sub-steps of a step whenever row 0 carries no slack entry: env_step, g0_precompute) -- row 0 of the matrix
+// handed over already holds the reflector vector, the rows below are already updated, pre_d0 / pre_tau0 are its
+// beta / tau.  Saves the reflector generation and its application to M - 1 rows in every sub-step.
+template <typename T, int M, int N, int LN, bool PRE0 = false, typename AF, typename A0F, typename YF>
 __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, A0F&& a0get, YF&& yget, T& x0,
                                                            T (&x)[split_slots(N, LN)], T (&nb0)[N - M],
-                                                           T (&nb)[split_slots(N, LN)][N - M], const int lq) {
+                                                           T (&nb)[split_slots(N, LN)][N - M], const int lq,
+                                                           const T pre_d0 = T(0), const T pre_tau0 = T(0)) {
     constexpr int S = split_slots(N, LN), K = N - M;
     constexpr int MP = (M + 1) / 2;          // row pairs (a zero row pads an odd M: it is a fixed point of every step)
     constexpr int KP = (K + 2) / 2;          // pairs over the K null vectors + x
@@ -289,6 +294,10 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, A0F&& a0ge
         T vrow[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) vrow[s] = a2[s][pi][hi];
+        constexpr bool pre = first && PRE0;                           // G(0) came with the matrix
+        if constexpr (pre) { d[0] = pre_d0; taup[0] = pre_tau0; }
+        T tp = pre_tau0;
+        if constexpr (!pre) {
         T part;
         if constexpr (first) {
             part = vrow[0] * vrow[0];
@@ -303,7 +312,7 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, A0F&& a0ge
         T alpha;
         if constexpr (first) alpha = c0[0].x;
         else alpha = qfrom<li, LN>(vrow[si]);
-        T beta, tp;
+        T beta;
         const T sc = larfg_scale(alpha, ss, beta, tp);
         d[i] = beta;
         taup[i] = tp;
@@ -317,9 +326,11 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, A0F&& a0ge
             else vrow[s] *= sc;
             a2[s][pi][hi] = vrow[s];
         }
+        }   // !pre
         if constexpr (i < M - 1) {
             constexpr int p0 = (i + 1) / 2;        // first row pair holding a row > i
             ATACOM_MARK("G_apply");
+            if constexpr (!pre) {
             // rows > i, processed in groups of (up to) 3 row pairs so that their quad sums share one DPP sequence
             static_for<0, (MP - p0 + 2) / 3>([&](auto gc) {
                 constexpr int pa = p0 + 3 * decltype(gc)::value;
@@ -342,6 +353,7 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, A0F&& a0ge
                     for (int s = s0; s < S; ++s) a2[s][pa + j] = fma2(-w[j], splat2(vrow[s]), a2[s][pa + j]);
                 }
             });
+            }   // !pre
             // ---- left reflector H(i) from column i, rows i+1..M-1: the replicated column for i == 0 (no broadcast),
             // slot si of lane li otherwise.  u over the pairs p0..: 0 for rows <= i, 1 at row i+1, scaled entries below
             ATACOM_MARK("H_larfg");
@@ -597,18 +609,21 @@ __device__ __forceinline__ void rref_apply_quad_inl(T (&nb0)[K], T (&nb)[split_s
 // is exact as float, as double with HOLD = true, and as double with either piece outlined) -- found by
 // tests/test_gpu_parity.py::test_refresh_and_exact_bias_variants_against_oracle.  Outlining keeps the double kernels
 // far from the register ceiling; their speed is irrelevant.
-template <typename T, int M, int N, int LN, typename AF, typename A0F, typename YF>
+template <typename T, int M, int N, int LN, bool PRE0, typename AF, typename A0F, typename YF>
 __device__ __attribute__((noinline)) void bidiag_solve_null_quad_out(AF& aget, A0F& a0get, YF& yget, T& x0,
                                                                      T (&x)[split_slots(N, LN)], T (&nb0)[N - M],
-                                                                     T (&nb)[split_slots(N, LN)][N - M], const int lq) {
-    bidiag_solve_null_quad_inl<T, M, N, LN>(aget, a0get, yget, x0, x, nb0, nb, lq);
+                                                                     T (&nb)[split_slots(N, LN)][N - M], const int lq,
+                                                                     const T pre_d0, const T pre_tau0) {
+    bidiag_solve_null_quad_inl<T, M, N, LN, PRE0>(aget, a0get, yget, x0, x, nb0, nb, lq, pre_d0, pre_tau0);
 }
-template <typename T, int M, int N, int LN = 4, typename AF, typename A0F, typename YF>
+template <typename T, int M, int N, int LN = 4, bool PRE0 = false, typename AF, typename A0F, typename YF>
 __device__ __forceinline__ void bidiag_solve_null_quad(AF&& aget, A0F&& a0get, YF&& yget, T& x0,
                                                        T (&x)[split_slots(N, LN)], T (&nb0)[N - M],
-                                                       T (&nb)[split_slots(N, LN)][N - M], const int lq) {
-    if constexpr (std::is_same<T, double>::value) bidiag_solve_null_quad_out<T, M, N, LN>(aget, a0get, yget, x0, x, nb0, nb, lq);
-    else bidiag_solve_null_quad_inl<T, M, N, LN>(aget, a0get, yget, x0, x, nb0, nb, lq);
+                                                       T (&nb)[split_slots(N, LN)][N - M], const int lq,
+                                                       const T pre_d0 = T(0), const T pre_tau0 = T(0)) {
+    if constexpr (std::is_same<T, double>::value)
+        bidiag_solve_null_quad_out<T, M, N, LN, PRE0>(aget, a0get, yget, x0, x, nb0, nb, lq, pre_d0, pre_tau0);
+    else bidiag_solve_null_quad_inl<T, M, N, LN, PRE0>(aget, a0get, yget, x0, x, nb0, nb, lq, pre_d0, pre_tau0);
 }
 template <typename T, int N, int K, int LN>
 __device__ __attribute__((noinline)) void rref_apply_quad_out(T (&nb0)[K], T (&nb)[split_slots(N, LN)][K],
