@@ -25,6 +25,7 @@ import os
 import sys
 import time
 
+sys.dont_write_bytecode = True                   # /root/reference is read-only for this build: no __pycache__ into it
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))

@@ -63,15 +63,19 @@ constexpr int kStatBlocks = 256;
 // kernel mapping policy for lanes_per_env = 0, from measurements on MI355X (profiles/r02_lanes_vs_batch.md): the fewer
 // lanes an environment is spread over, the fewer instructions in total but the more per wave; a mapping's step time is
 // flat while its waves still find a SIMD each (1024 SIMDs) and doubles beyond.  So: the widest mapping whose waves fit --
-// quad up to 16384 envs (1024 waves), pair up to 32768, lane beyond.  The 8-lane mapping (12 % fewer instructions per
-// wave than the quad) is available on request but never chosen: with every CU busy the clock drops by ~5 % and its waves
-// park longer behind three-level DPP reductions -- 29.3 vs 28.4 us at 8192 envs, a tie at <= 4096 -- and the policy-
-// rollout kernels (GEMM blocks of 16 environments) have no 8-lane form, so the choice would differ between kernels.
+// iiwa: 8 lanes up to 8192 envs (1024 waves), quad up to 16384, pair up to 32768, lane beyond.  (The 8-lane mapping has
+// 10 % fewer instructions per wave than the quad; until the state buffer moved to groups of four fields -- 9 wide loads
+// and stores per lane instead of 68 narrow ones, atacom_kernels.h -- its 1024 waves lost that advantage in the memory
+// pipeline: 28.8 vs 27.5 us at 8192 envs before, 26.1 vs 27.4 us after.)  planar (6 x 9): the quad is the widest that
+// pays.  The policy-rollout kernels (GEMM blocks of 16 environments = quads) have no 8-lane form and run the quad
+// mapping on the same handle -- the state layout does not depend on the mapping.
 int pick_lanes(const atacom_config& c) {
     if (c.lanes_per_env == 1 || c.lanes_per_env == 2 || c.lanes_per_env == 4 || c.lanes_per_env == 8)
         return c.lanes_per_env;
     if (c.dtype == ATACOM_F64) return 1;
-    if (c.env_id == ATACOM_ENV_IIWA || c.env_id == ATACOM_ENV_PLANAR)      // iiwa: 28 / 37 / 53 us per step
+    if (c.env_id == ATACOM_ENV_IIWA)                                       // 26 / 27.5 / 37 / 53 us per step
+        return c.batch <= 8192 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));
+    if (c.env_id == ATACOM_ENV_PLANAR)
         return c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1);
     return 1;                                                              // circle: launch-bound either way
 }

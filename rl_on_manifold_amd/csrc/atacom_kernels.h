@@ -1,8 +1,9 @@
 // Kernels of the batched ATACOM step, templated on the scalar type and the environment.
 //
 // Mapping (DESIGN.md "Kernel design"): ONE ENVIRONMENT PER LANE, 64 consecutive environments per
-// wavefront, one wavefront per workgroup.  Persistent per-env state lives in HBM as structure-of-arrays
-// planes [field][env] so a wave's loads/stores of one field are a single coalesced 256-B (f32) segment;
+// wavefront, one wavefront per workgroup (or 2 / 4 / 8 lanes per environment: atacom_quad.h).  Persistent per-env
+// state lives in HBM as one 16-byte-aligned record per environment, read and written with dwordx4 accesses off one
+// address (see Planes below for why not field planes);
 // all per-env matrices (J_c 12x17, null basis 17x5, ...) live in VGPRs -- the kernels are compiled for
 // one wave per SIMD (__launch_bounds__(64)) to get the full 512-register budget.
 // The four physics sub-steps of an env step, the observation / reward / termination logic and the
@@ -25,18 +26,48 @@ constexpr int WAVE = 64;
 #endif
 template <int LANES> constexpr int BLOCK = (LANES > 1) ? ATACOM_BLOCK_GROUP : 64;
 
-// ------------------------------------------------------------------ plane layout of the state buffer
+// ------------------------------------------------------------------ layout of the per-handle state buffer
+// Fields are kept in GROUPS OF FOUR: [group][env][4] -- a lane reads / writes 16 consecutive bytes (global_load_dwordx4 /
+// global_store_dwordx4), the environments of a wave are 16 bytes apart, so every access instruction of a wave is one
+// contiguous, fully used segment (1 KB with one environment per lane) however the environments are mapped to lanes.
+// Two regions of the one allocation:
+//   hot   the fields a step reads and writes back: q, dq, s, puck, the hit bookkeeping, the statistics accumulators --
+//         34 values for the iiwa task = 9 groups (2 pad values);
+//   cold  the initial state a reset restores (and the servo joints of the rigid-body mode).
+// History (profiles/r02_lanes_vs_batch.md): single-field planes [field][env] (round 1) cost one 64-bit per-lane address
+// per field, computed up front for the loads, kept alive over the whole step for the store tail and therefore parked in
+// AGPRs -- ~290 vector instructions and 68 memory instructions per step of the iiwa kernels; one record per
+// environment [env][36] (one address, 9 dwordx4) was 4.5 % faster for the 8-lane mapping but 7 % slower for one
+// environment per lane at 65536 environments, where a wave's 64 records are 144 bytes apart and no single access is
+// contiguous.  Groups of four keep the wide accesses and the coalescing.
+// Field numbering is unchanged from the plane era ("plane" = field index); pl() maps it to the buffer.
 template <typename E>
 struct Planes {
-    static constexpr int Q = 0, DQ = Q + E::NQ, S = DQ + E::NQ, PUCK = S + E::NG, RHIT = PUCK + 6,
-                         VHX = RHIT + 1, IQ = VHX + 1, IDQ = IQ + E::NQ, IS = IDQ + E::NQ, IPUCK = IS + E::NG,
-                         SSUM = IPUCK + 6, SCMAX = SSUM + 1, SDQMAX = SCMAX + 1,
+    static constexpr int Q = 0, DQ = Q + E::NQ, S = DQ + E::NQ, PUCK = S + E::NG, RHIT = PUCK + 6, VHX = RHIT + 1,
+                         SSUM = VHX + 1, SCMAX = SSUM + 1, SDQMAX = SCMAX + 1, HOT = SDQMAX + 1,
+                         IQ = HOT, IDQ = IQ + E::NQ, IS = IDQ + E::NQ, IPUCK = IS + E::NG,
                          // row N4 (iiwa): the three servo joints of the rigid-body mode, positions then velocities
-                         QX = SDQMAX + 1, DQX = QX + 3, COUNT = (E::ID == 2) ? DQX + 3 : SDQMAX + 1;
+                         QX = IPUCK + 6, DQX = QX + 3, COUNT = (E::ID == 2) ? DQX + 3 : QX;
+    static constexpr int HOT_LD = (HOT + 3) / 4 * 4, COLD_LD = (COUNT - HOT + 3) / 4 * 4;
+    static constexpr int VALUES_PER_ENV = HOT_LD + COLD_LD;          // allocation: VALUES_PER_ENV * batch elements
     static constexpr int I_HIT = 0, I_T = 1, I_CNT = 2, I_EP = 3, ICOUNT = 4;   // I_EP: episodes started (RNG counter)
     static constexpr int STATE_DIM = 2 * E::NQ + E::NG + 6 + 4;
     static constexpr int INIT_DIM = 2 * E::NQ + (E::PUCK ? 6 : 0);
 };
+// field `plane` of environment b (buffers come from hipMalloc: 256-byte aligned; every group element is 16-byte aligned)
+template <typename E, typename V>
+__device__ __forceinline__ V& pl(V* f, int plane, int B, int b) {
+    using L = Planes<E>;
+    V* a = static_cast<V*>(__builtin_assume_aligned(f, 16));
+    const int p = (plane < L::HOT) ? plane : plane - L::HOT + L::HOT_LD;      // cold groups follow the hot ones
+    return a[((size_t)(p / 4) * B + b) * 4 + (p % 4)];
+}
+// the integer fields: one int4 per environment
+template <typename V>
+__device__ __forceinline__ V& pli(V* ip, int plane, int b) {
+    V* a = static_cast<V*>(__builtin_assume_aligned(ip, 16));
+    return a[(size_t)b * 4 + plane];
+}
 
 // Packed rollout record of one (step, env): the (s, a, r, s', absorbing, last) tuple mushroom_rl.Core collects, as ONE
 // run of F floats -- the layout the sharded collector all-gathers without a repacking pass (rollout.py).
@@ -59,13 +90,13 @@ template <typename T, typename E>
 __device__ __forceinline__ void load_aux(const T* __restrict__ f, int B, int b, EnvState<T, E>& st) {
     using L = Planes<E>;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { st.qx[i] = f[(L::QX + i) * (size_t)B + b]; st.dqx[i] = f[(L::DQX + i) * (size_t)B + b]; }
+    for (int i = 0; i < 3; ++i) { st.qx[i] = pl<E>(f, L::QX + i, B, b); st.dqx[i] = pl<E>(f, L::DQX + i, B, b); }
 }
 template <typename T, typename E>
 __device__ __forceinline__ void store_aux(T* __restrict__ f, int B, int b, const EnvState<T, E>& st) {
     using L = Planes<E>;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { f[(L::QX + i) * (size_t)B + b] = st.qx[i]; f[(L::DQX + i) * (size_t)B + b] = st.dqx[i]; }
+    for (int i = 0; i < 3; ++i) { pl<E>(f, L::QX + i, B, b) = st.qx[i]; pl<E>(f, L::DQX + i, B, b) = st.dqx[i]; }
 }
 
 template <typename T>
@@ -80,22 +111,22 @@ __device__ __forceinline__ void load_state(const T* __restrict__ f, const int* _
                                            EnvState<T, E>& st) {
     using L = Planes<E>;
 #pragma unroll
-    for (int i = 0; i < E::NQ; ++i) { st.q[i] = f[(L::Q + i) * (size_t)B + b]; st.dq[i] = f[(L::DQ + i) * (size_t)B + b]; }
+    for (int i = 0; i < E::NQ; ++i) { st.q[i] = pl<E>(f, L::Q + i, B, b); st.dq[i] = pl<E>(f, L::DQ + i, B, b); }
 #pragma unroll
-    for (int i = 0; i < E::NG; ++i) st.s[i] = f[(L::S + i) * (size_t)B + b];
+    for (int i = 0; i < E::NG; ++i) st.s[i] = pl<E>(f, L::S + i, B, b);
     if (E::PUCK) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) st.puck[i] = f[(L::PUCK + i) * (size_t)B + b];
-        st.r_hit = f[L::RHIT * (size_t)B + b];
-        st.vel_hit_x = f[L::VHX * (size_t)B + b];
-        st.has_hit = ip[L::I_HIT * (size_t)B + b];
+        for (int i = 0; i < 6; ++i) st.puck[i] = pl<E>(f, L::PUCK + i, B, b);
+        st.r_hit = pl<E>(f, L::RHIT, B, b);
+        st.vel_hit_x = pl<E>(f, L::VHX, B, b);
+        st.has_hit = pli(ip, L::I_HIT, b);
     } else {
 #pragma unroll
         for (int i = 0; i < 6; ++i) st.puck[i] = T(0);
         st.r_hit = st.vel_hit_x = T(0);
         st.has_hit = 0;
     }
-    st.t = ip[L::I_T * (size_t)B + b];
+    st.t = pli(ip, L::I_T, b);
 }
 
 template <typename T, typename E>
@@ -103,28 +134,28 @@ __device__ __forceinline__ void store_state(T* __restrict__ f, int* __restrict__
                                             const EnvState<T, E>& st) {
     using L = Planes<E>;
 #pragma unroll
-    for (int i = 0; i < E::NQ; ++i) { f[(L::Q + i) * (size_t)B + b] = st.q[i]; f[(L::DQ + i) * (size_t)B + b] = st.dq[i]; }
+    for (int i = 0; i < E::NQ; ++i) { pl<E>(f, L::Q + i, B, b) = st.q[i]; pl<E>(f, L::DQ + i, B, b) = st.dq[i]; }
 #pragma unroll
-    for (int i = 0; i < E::NG; ++i) f[(L::S + i) * (size_t)B + b] = st.s[i];
+    for (int i = 0; i < E::NG; ++i) pl<E>(f, L::S + i, B, b) = st.s[i];
     if (E::PUCK) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) f[(L::PUCK + i) * (size_t)B + b] = st.puck[i];
-        f[L::RHIT * (size_t)B + b] = st.r_hit;
-        f[L::VHX * (size_t)B + b] = st.vel_hit_x;
-        ip[L::I_HIT * (size_t)B + b] = st.has_hit;
+        for (int i = 0; i < 6; ++i) pl<E>(f, L::PUCK + i, B, b) = st.puck[i];
+        pl<E>(f, L::RHIT, B, b) = st.r_hit;
+        pl<E>(f, L::VHX, B, b) = st.vel_hit_x;
+        pli(ip, L::I_HIT, b) = st.has_hit;
     }
-    ip[L::I_T * (size_t)B + b] = st.t;
+    pli(ip, L::I_T, b) = st.t;
 }
 
 template <typename T, typename E>
 __device__ __forceinline__ void load_init(const T* __restrict__ f, int B, int b, EnvState<T, E>& st) {
     using L = Planes<E>;
 #pragma unroll
-    for (int i = 0; i < E::NQ; ++i) { st.q[i] = f[(L::IQ + i) * (size_t)B + b]; st.dq[i] = f[(L::IDQ + i) * (size_t)B + b]; }
+    for (int i = 0; i < E::NQ; ++i) { st.q[i] = pl<E>(f, L::IQ + i, B, b); st.dq[i] = pl<E>(f, L::IDQ + i, B, b); }
 #pragma unroll
-    for (int i = 0; i < E::NG; ++i) st.s[i] = f[(L::IS + i) * (size_t)B + b];
+    for (int i = 0; i < E::NG; ++i) st.s[i] = pl<E>(f, L::IS + i, B, b);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) st.puck[i] = E::PUCK ? f[(L::IPUCK + i) * (size_t)B + b] : T(0);
+    for (int i = 0; i < 6; ++i) st.puck[i] = E::PUCK ? pl<E>(f, L::IPUCK + i, B, b) : T(0);
     st.r_hit = st.vel_hit_x = T(0);
     st.has_hit = 0;
     st.t = 0;
@@ -183,8 +214,8 @@ __device__ __forceinline__ void reset_env(const Params<T>& P, const T* __restric
     using L = Planes<E>;
     load_init<T, E>(f, B, b, st);
     if (!P.random_init) return;
-    const int ep = ip[L::I_EP * (size_t)B + b];
-    if (commit) ip[L::I_EP * (size_t)B + b] = ep + 1;     // commit = false: a lane shadowing another lane's environment
+    const int ep = pli(ip, L::I_EP, b);
+    if (commit) pli(ip, L::I_EP, b) = ep + 1;     // commit = false: a lane shadowing another lane's environment
     if (E::ID == 0) {
         // circle_base.py:36-42
         const T y = T(-0.5) + T(1.5) * device_uniform<T>(P.seed, b, ep, 0);
@@ -586,9 +617,9 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     load_state<T, E>(f, ip, B, b, st);
     // the statistics accumulators are read up front with the rest of the state: a read-modify-write at the end
     // would make the store tail wait on loads queued behind ~60 stores (vmcnt counts both on gfx9-class hardware)
-    const T ssum0 = f[L::SSUM * (size_t)B + b], scmax0 = f[L::SCMAX * (size_t)B + b];
-    const T sdq0 = f[L::SDQMAX * (size_t)B + b];
-    const int cnt0 = ip[L::I_CNT * (size_t)B + b];
+    const T ssum0 = pl<E>(f, L::SSUM, B, b), scmax0 = pl<E>(f, L::SCMAX, B, b);
+    const T sdq0 = pl<E>(f, L::SDQMAX, B, b);
+    const int cnt0 = pli(ip, L::I_CNT, b);
     T act[E::NK];
 #pragma unroll
     for (int k = 0; k < E::NK; ++k) act[k] = action[(size_t)b * E::NK + k];
@@ -601,10 +632,10 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     reward[b] = out.reward;
     absorbing[b] = out.absorbing ? 1 : 0;
     if (last) last[b] = out.last ? 1 : 0;
-    f[L::SSUM * (size_t)B + b] = ssum0 + out.log_avg;
-    f[L::SCMAX * (size_t)B + b] = num<T>::max(scmax0, out.log_max);
-    f[L::SDQMAX * (size_t)B + b] = num<T>::max(sdq0, out.log_dq);
-    ip[L::I_CNT * (size_t)B + b] = cnt0 + 1;
+    pl<E>(f, L::SSUM, B, b) = ssum0 + out.log_avg;
+    pl<E>(f, L::SCMAX, B, b) = num<T>::max(scmax0, out.log_max);
+    pl<E>(f, L::SDQMAX, B, b) = num<T>::max(sdq0, out.log_dq);
+    pli(ip, L::I_CNT, b) = cnt0 + 1;
     if (P.auto_reset && out.last) reset_env<T, E>(P, f, ip, B, b, st);
     store_state<T, E>(f, ip, B, b, st);
     if constexpr (DYN) store_aux<T, E>(f, B, b, st);
@@ -626,7 +657,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
     EnvState<T, E> st;
     load_state<T, E>(f, ip, B, b, st);
     if constexpr (DYN) load_aux<T, E>(f, B, b, st);
-    T ssum = T(0), scmax = f[L::SCMAX * (size_t)B + b], sdq = f[L::SDQMAX * (size_t)B + b];
+    T ssum = T(0), scmax = pl<E>(f, L::SCMAX, B, b), sdq = pl<E>(f, L::SDQMAX, B, b);
 #pragma unroll 1
     for (int t = 0; t < n_steps; ++t) {
         const size_t row = (size_t)t * B + b;
@@ -664,10 +695,10 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
         if (P.auto_reset && out.last) reset_env<T, E>(P, f, ip, B, b, st);
     }
     if (lq != 0) return;
-    f[L::SSUM * (size_t)B + b] += ssum;
-    f[L::SCMAX * (size_t)B + b] = scmax;
-    f[L::SDQMAX * (size_t)B + b] = sdq;
-    ip[L::I_CNT * (size_t)B + b] += n_steps;
+    pl<E>(f, L::SSUM, B, b) += ssum;
+    pl<E>(f, L::SCMAX, B, b) = scmax;
+    pl<E>(f, L::SDQMAX, B, b) = sdq;
+    pli(ip, L::I_CNT, b) += n_steps;
     store_state<T, E>(f, ip, B, b, st);
     if constexpr (DYN) store_aux<T, E>(f, B, b, st);
 }
@@ -721,7 +752,7 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
     const int erow = lane / LANES;                                             // own environment within the wavefront
     EnvState<T, E> st;
     load_state<T, E>(f, ip, B, b, st);
-    T ssum = T(0), scmax = f[L::SCMAX * (size_t)B + b], sdq = f[L::SDQMAX * (size_t)B + b];
+    T ssum = T(0), scmax = pl<E>(f, L::SCMAX, B, b), sdq = pl<E>(f, L::SDQMAX, B, b);
 #pragma unroll 1
     for (int t = 0; t < n_steps; ++t) {
         const size_t row = (size_t)t * B + b;
@@ -784,10 +815,10 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
         if (P.auto_reset && out.last) reset_env<T, E>(P, f, ip, B, b, st, valid);
     }
     if (lq != 0 || !valid) return;
-    f[L::SSUM * (size_t)B + b] += ssum;
-    f[L::SCMAX * (size_t)B + b] = scmax;
-    f[L::SDQMAX * (size_t)B + b] = sdq;
-    ip[L::I_CNT * (size_t)B + b] += n_steps;
+    pl<E>(f, L::SSUM, B, b) += ssum;
+    pl<E>(f, L::SCMAX, B, b) = scmax;
+    pl<E>(f, L::SDQMAX, B, b) = sdq;
+    pli(ip, L::I_CNT, b) += n_steps;
     store_state<T, E>(f, ip, B, b, st);
 }
 
@@ -806,18 +837,18 @@ __global__ void __launch_bounds__(WAVE) k_reset(const Params<T> P, T* __restrict
             const T* row = init + (size_t)b * L::INIT_DIM;
 #pragma unroll
             for (int i = 0; i < E::NQ; ++i) {
-                f[(L::IQ + i) * (size_t)B + b] = row[i];
-                f[(L::IDQ + i) * (size_t)B + b] = row[E::NQ + i];
+                pl<E>(f, L::IQ + i, B, b) = row[i];
+                pl<E>(f, L::IDQ + i, B, b) = row[E::NQ + i];
             }
             if (E::PUCK) {
 #pragma unroll
-                for (int i = 0; i < 6; ++i) f[(L::IPUCK + i) * (size_t)B + b] = row[2 * E::NQ + i];
+                for (int i = 0; i < 6; ++i) pl<E>(f, L::IPUCK + i, B, b) = row[2 * E::NQ + i];
             }
         }
         load_init<T, E>(f, B, b, st);
         slack_init<T, E>(P, st);                 // slack of the STORED initial state (reused by every auto-reset)
 #pragma unroll
-        for (int g = 0; g < E::NG; ++g) f[(L::IS + g) * (size_t)B + b] = st.s[g];
+        for (int g = 0; g < E::NG; ++g) pl<E>(f, L::IS + g, B, b) = st.s[g];
         if (P.random_init && !init) reset_env<T, E>(P, f, ip, B, b, st);     // an explicit state wins over the draw
         store_state<T, E>(f, ip, B, b, st);
         if constexpr (E::ID == 2) store_aux<T, E>(f, B, b, st);              // servo joints back to rest
@@ -834,9 +865,9 @@ __global__ void k_fill_init(int B, T* __restrict__ f, int* __restrict__ ip, cons
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
 #pragma unroll
-    for (int i = 0; i < E::NQ; ++i) { f[(L::IQ + i) * (size_t)B + b] = row[i]; f[(L::IDQ + i) * (size_t)B + b] = row[E::NQ + i]; }
+    for (int i = 0; i < E::NQ; ++i) { pl<E>(f, L::IQ + i, B, b) = row[i]; pl<E>(f, L::IDQ + i, B, b) = row[E::NQ + i]; }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) f[(L::IPUCK + i) * (size_t)B + b] = row[2 * E::NQ + i];
+    for (int i = 0; i < 6; ++i) pl<E>(f, L::IPUCK + i, B, b) = row[2 * E::NQ + i];
 }
 
 template <typename T, typename E>
@@ -844,10 +875,10 @@ __global__ void k_clear_stats(int B, T* __restrict__ f, int* __restrict__ ip) {
     using L = Planes<E>;
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    f[L::SSUM * (size_t)B + b] = T(0);
-    f[L::SCMAX * (size_t)B + b] = -INFINITY;
-    f[L::SDQMAX * (size_t)B + b] = -INFINITY;
-    ip[L::I_CNT * (size_t)B + b] = 0;
+    pl<E>(f, L::SSUM, B, b) = T(0);
+    pl<E>(f, L::SCMAX, B, b) = -INFINITY;
+    pl<E>(f, L::SDQMAX, B, b) = -INFINITY;
+    pli(ip, L::I_CNT, b) = 0;
 }
 
 // per-block partial reduction of the statistics: partial[block] = {sum, count, cmax, dqmax} (doubles)
@@ -858,10 +889,10 @@ __global__ void __launch_bounds__(256) k_stats(int B, const T* __restrict__ f, c
     __shared__ double sh[4][256];
     double s = 0.0, c = 0.0, m1 = -INFINITY, m2 = -INFINITY;
     for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) {
-        s += (double)f[L::SSUM * (size_t)B + b];
-        c += (double)ip[L::I_CNT * (size_t)B + b];
-        m1 = fmax(m1, (double)f[L::SCMAX * (size_t)B + b]);
-        m2 = fmax(m2, (double)f[L::SDQMAX * (size_t)B + b]);
+        s += (double)pl<E>(f, L::SSUM, B, b);
+        c += (double)pli(ip, L::I_CNT, b);
+        m1 = fmax(m1, (double)pl<E>(f, L::SCMAX, B, b));
+        m2 = fmax(m2, (double)pl<E>(f, L::SDQMAX, B, b));
     }
     sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = c; sh[2][threadIdx.x] = m1; sh[3][threadIdx.x] = m2;
     __syncthreads();
@@ -934,7 +965,7 @@ __global__ void k_get_aux(int B, const T* __restrict__ f, T* __restrict__ out) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) out[(size_t)b * 6 + i] = f[(L::QX + i) * (size_t)B + b];
+    for (int i = 0; i < 6; ++i) out[(size_t)b * 6 + i] = pl<E>(f, L::QX + i, B, b);
 }
 template <typename T, typename E>
 __global__ void k_set_aux(int B, T* __restrict__ f, const T* __restrict__ in) {
@@ -942,7 +973,7 @@ __global__ void k_set_aux(int B, T* __restrict__ f, const T* __restrict__ in) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) f[(L::QX + i) * (size_t)B + b] = in[(size_t)b * 6 + i];
+    for (int i = 0; i < 6; ++i) pl<E>(f, L::QX + i, B, b) = in[(size_t)b * 6 + i];
 }
 
 // row N4 primitives (atacom_inverse_dynamics / atacom_forward_dynamics)

@@ -174,7 +174,7 @@ struct Ops {
                            (const T*)q, (const T*)dq, (T*)fun, (T*)J, (T*)b);
     }
     static const EnvOps* table() {
-        static const EnvOps ops = {L::COUNT, L::ICOUNT, L::STATE_DIM, L::INIT_DIM, E::OBS, E::NQ, E::NF, E::NG, E::NK,
+        static const EnvOps ops = {L::VALUES_PER_ENV, L::ICOUNT, L::STATE_DIM, L::INIT_DIM, E::OBS, E::NQ, E::NF, E::NG, E::NK,
                                    sizeof(T), &step, &rollout, &rollout_mlp, &reset, &fill_init, &clear_stats, &stats,
                                    &get_state, &set_state, &nullspace, &terms};
         return &ops;

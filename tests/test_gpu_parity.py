@@ -416,8 +416,10 @@ def test_policy_rollout_multi_step_consistency(golden):
     """T-step policy rollout == feeding the actions it drew to the plain rollout kernel; deterministic without noise."""
     B, T = 192, 10
     dev, _ = _policy_pair(golden, 'ppo_iiwa')
-    e1 = _env('iiwa', B, 'f32', auto_reset=True, horizon=4)
-    e2 = _env('iiwa', B, 'f32', auto_reset=True, horizon=4)
+    # the policy kernels run the quad mapping (GEMM blocks of 16 environments); the plain rollout they are compared
+    # with must use the same mapping for the two to agree to rounding (the automatic choice at this batch is 8 lanes)
+    e1 = _env('iiwa', B, 'f32', auto_reset=True, horizon=4, lanes_per_env=4)
+    e2 = _env('iiwa', B, 'f32', auto_reset=True, horizon=4, lanes_per_env=4)
     gen = torch.Generator(device=DEV); gen.manual_seed(1)
     eps = torch.randn((T, B, 5), device=DEV, generator=gen)
     o1 = e1.rollout_policy(dev, T, noise=eps)
