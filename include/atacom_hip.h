@@ -110,7 +110,7 @@ int atacom_default_config(int32_t env_id, atacom_config* out);
 int atacom_get_dims(int32_t env_id, atacom_dims* out);
 
 /* Replaces constructing the wrapper + base env (atacom.py:10-79; circle_base.py:18-31; env_hitting.py:8-21).
- * Allocates the persistent per-env state (structure-of-arrays planes) on `device`. */
+ * Allocates the persistent per-env state (fields in groups of four, [group][env][4]) on `device`. */
 int atacom_create(const atacom_config* cfg, int device, atacom_handle** out);
 int atacom_destroy(atacom_handle* h);
 

@@ -62,19 +62,21 @@ constexpr int kStatBlocks = 256;
 
 // kernel mapping policy for lanes_per_env = 0, from measurements on MI355X (profiles/r02_lanes_vs_batch.md): the fewer
 // lanes an environment is spread over, the fewer instructions in total but the more per wave; a mapping's step time is
-// flat while its waves still find a SIMD each (1024 SIMDs) and doubles beyond.  So: the widest mapping whose waves fit --
-// iiwa: 8 lanes up to 8192 envs (1024 waves), quad up to 16384, pair up to 32768, lane beyond.  (The 8-lane mapping has
-// 10 % fewer instructions per wave than the quad; until the state buffer moved to groups of four fields -- 9 wide loads
-// and stores per lane instead of 68 narrow ones, atacom_kernels.h -- its 1024 waves lost that advantage in the memory
-// pipeline: 28.8 vs 27.5 us at 8192 envs before, 26.1 vs 27.4 us after.)  planar (6 x 9): the quad is the widest that
-// pays.  The policy-rollout kernels (GEMM blocks of 16 environments = quads) have no 8-lane form and run the quad
-// mapping on the same handle -- the state layout does not depend on the mapping.
+// flat while its waves still find a SIMD each (1024 SIMDs) and doubles beyond.  iiwa: 8 lanes up to 4096 envs, quad up to
+// 16384, pair up to 32768, lane beyond.  The 8-lane mapping has 13 % fewer instructions per wave than the quad and wins
+// wherever it leaves half of the chip idle like the quad does at twice the batch (26.1 vs 26.9 us per step at 4096 envs,
+// rollout kernel 23.1 vs 24.5 us per step, on every box tried).  At 8192 envs its 1024 waves occupy every CU, the shader
+// clock drops and the launch / load / store phase of a step grows by ~1 us: over nine boxes the two mappings tied on
+// average (27.2 us both; per box the 8-lane mapping ranged from 5 % faster to 4.5 % slower), so the quad -- same speed,
+// half the chip left free for a learner's kernels on another stream -- keeps that range.  planar (6 x 9): the quad is
+// the widest that pays.  The policy-rollout kernels (GEMM blocks of 16 environments = quads) have no 8-lane form and run
+// the quad mapping on the same handle -- the state layout does not depend on the mapping.
 int pick_lanes(const atacom_config& c) {
     if (c.lanes_per_env == 1 || c.lanes_per_env == 2 || c.lanes_per_env == 4 || c.lanes_per_env == 8)
         return c.lanes_per_env;
     if (c.dtype == ATACOM_F64) return 1;
-    if (c.env_id == ATACOM_ENV_IIWA)                                       // 26 / 27.5 / 37 / 53 us per step
-        return c.batch <= 8192 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));
+    if (c.env_id == ATACOM_ENV_IIWA)                                       // 26 / 27 / 37 / 53 us per step
+        return c.batch <= 4096 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));
     if (c.env_id == ATACOM_ENV_PLANAR)
         return c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1);
     return 1;                                                              // circle: launch-bound either way

@@ -20,6 +20,9 @@ namespace atacom {
 struct Circle {
     static constexpr int ID = 0, NQ = 2, NF = 1, NG = 1, NC = 2, NN = 3, NK = 1, OBS = 4, MODE = 0;
     static constexpr bool PUCK = false;
+    // jac_zero(r, i): entry (r, i) of the constraint Jacobian is STRUCTURALLY zero (constraint_terms writes a literal 0
+    // there), so the assembly of K J and J dq skips it at compile time -- the optimiser may not fold fma(K, 0, 0)
+    static constexpr bool jac_zero(int, int) { return false; }
 };
 struct CircleEC : Circle {      // CircleEnvErrorCorrection, circle_error_correction.py:7-21
     static constexpr int NK = 2, MODE = 1;
@@ -30,10 +33,13 @@ struct CircleT : Circle {       // CircleEnvTerminated, circle_terminated.py:8-2
 struct Planar {
     static constexpr int ID = 1, NQ = 3, NF = 0, NG = 6, NC = 6, NN = 9, NK = 3, OBS = 12, MODE = 0;
     static constexpr bool PUCK = true;
+    static constexpr bool jac_zero(int r, int i) { return r >= 3 && i != r - 3; }     // joint-limit rows: diagonal
 };
 struct Iiwa {
     static constexpr int ID = 2, NQ = 6, NF = 1, NG = 11, NC = 12, NN = 17, NK = 5, OBS = 18, MODE = 0;
     static constexpr bool PUCK = true;
+    // joint-limit rows 6..11: diagonal; row 4 (height of link_4): joints 3..6 do not move the frame
+    static constexpr bool jac_zero(int r, int i) { return (r >= 6 && i != r - 6) || (r == 4 && i >= 2); }
 };
 
 // Everything a kernel needs besides per-env state; passed by value (kernarg segment -> SGPRs).

@@ -335,9 +335,15 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
     constexpr int SQ = split_slots(NN, LGC);
     T Aq[NC][SQ];              // LANES > 1: this lane's columns of [K J | 0] (column c >= 1 -> lane (c-1) % LANES,
                                // slot (c-1) / LANES; column 0 is replicated and read from A directly, atacom_quad.h)
+    T tlo[NQ], tup[NQ];         // acc_truncation bounds (atacom.py:117-121): functions of the controller's dq only
     auto prepare = [&](int sub) {
 #pragma unroll
-            for (int i = 0; i < NQ; ++i) { qc[i] = st.q[i]; dqc[i] = st.dq[i]; }
+            for (int i = 0; i < NQ; ++i) {
+                qc[i] = st.q[i]; dqc[i] = st.dq[i];
+                // lo <= up always (K_q, vel_max > 0 and both are clamped into [-acc_max, acc_max])
+                tup[i] = num<T>::max(num<T>::min(P.acc_max[i], -P.Kq[i] * (dqc[i] - P.vel_max[i])), -P.acc_max[i]);
+                tlo[i] = num<T>::min(num<T>::max(-P.acc_max[i], -P.Kq[i] * (dqc[i] + P.vel_max[i])), P.acc_max[i]);
+            }
             T fun[NC], J[NC][NQ], bst[NC];
             ATACOM_MARK("PRE_terms");
             constraint_terms(E{}, P, qc, dqc, fun, J, bst);
@@ -353,6 +359,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 T jdq = T(0);
 #pragma unroll
                 for (int i = 0; i < NQ; ++i) {
+                    if (E::jac_zero(r, i)) { A[r][i] = T(0); continue; }     // compile time (r, i are unrolled)
                     jdq = num<T>::fma(J[r][i], dqc[i], jdq);
                     // constraints.py:39-40; the "+ 0" inside the FMA turns a -0 product into +0 exactly as the
                     // reference's diag(K) @ J matmul does (the sign of a zero steers dlarfg's sign choice)
@@ -379,7 +386,8 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 for (int r = 1; r < NC; ++r) {
                     T w = A[r][0];
 #pragma unroll
-                    for (int c = 1; c < NQ; ++c) w = num<T>::fma(A[r][c], A[0][c], w);
+                    for (int c = 1; c < NQ; ++c)
+                        if (!E::jac_zero(r, c)) w = num<T>::fma(A[r][c], A[0][c], w);    // structural zeros add nothing
                     w *= g0_tau;
                     A[r][0] -= w;
 #pragma unroll
@@ -483,11 +491,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
         for (int g = 0; g < NG; ++g) st.s[g] = num<T>::fma(mu[NQ + g], P.dt, st.s[g]);   // :135
         T ddq[NQ];
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {                          // acc_truncation, atacom.py:117-121
-            const T up = num<T>::max(num<T>::min(P.acc_max[i], -P.Kq[i] * (dqc[i] - P.vel_max[i])), -P.acc_max[i]);
-            const T lo = num<T>::min(num<T>::max(-P.acc_max[i], -P.Kq[i] * (dqc[i] + P.vel_max[i])), P.acc_max[i]);
-            ddq[i] = num<T>::min(num<T>::max(mu[i], lo), up);
-        }
+        for (int i = 0; i < NQ; ++i) ddq[i] = num<T>::clamp(mu[i], tlo[i], tup[i]);   // acc_truncation, atacom.py:117-121
         if (E::ID == 0) {
             // circle_atacom.py:26-27 + circle_base.py:59-63
 #pragma unroll
@@ -504,7 +508,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 const T vlim = T(1.5) * P.vel_max[i];
-                st.dq[i] = num<T>::min(num<T>::max(num<T>::fma(ddq[i], P.dt, st.dq[i]), -vlim), vlim);
+                st.dq[i] = num<T>::clamp(num<T>::fma(ddq[i], P.dt, st.dq[i]), -vlim, vlim);
                 st.q[i] = num<T>::fma(st.dq[i], P.dt, st.q[i]);
             }
         }
@@ -607,6 +611,9 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
                                                const T* __restrict__ action, T* __restrict__ obs,
                                                T* __restrict__ reward, uint8_t* __restrict__ absorbing,
                                                uint8_t* __restrict__ last) {
+    // (kernarg preloading -- pointers and batch size first, -amdgpu-kernarg-preload-count=16 -- was tried: the waves no
+    // longer wait for a scalar load before their first state loads, but the step time did not move (27.5 us both ways)
+    // and the launch-bound circle kernel got slower, 7.4 -> 10.7 us: profiles/r02_lanes_vs_batch.md)
     using L = Planes<E>;
     const int B = P.batch;
     const int gt = blockIdx.x * BLOCK<LANES> + threadIdx.x;

@@ -81,6 +81,10 @@ template <> struct num<float> {
     static __device__ __forceinline__ float acos(float x) { return acosf(x); }
     static __device__ __forceinline__ float max(float a, float b) { return fmaxf(a, b); }
     static __device__ __forceinline__ float min(float a, float b) { return fminf(a, b); }
+    // min(max(x, lo), hi) for lo <= hi as ONE v_med3_f32.  fminf / fmaxf are lowered with a canonicalising
+    // v_max_f32 x, x, x in front of every operand the compiler cannot prove quiet (IEEE mode): 4-5 instructions per
+    // clamp in the sub-step loop.  A NaN x gives lo with both forms (v_med3 falls back to min3, which ignores NaNs).
+    static __device__ __forceinline__ float clamp(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 };
 template <> struct num<double> {
     static __device__ __forceinline__ double sqrt(double x) { return __builtin_sqrt(x); }
@@ -95,6 +99,7 @@ template <> struct num<double> {
     static __device__ __forceinline__ double acos(double x) { return ::acos(x); }
     static __device__ __forceinline__ double max(double a, double b) { return fmax(a, b); }
     static __device__ __forceinline__ double min(double a, double b) { return fmin(a, b); }
+    static __device__ __forceinline__ double clamp(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 };
 
 // compile-time loop: the body is instantiated once per index, so every array index below is a constant

@@ -515,11 +515,13 @@ __device__ __forceinline__ void rref_apply_quad_inl(T (&nb0)[K], T (&nb)[split_s
             const bool e = (cm > tol) && (col[s] >= j0);
             cand = e ? col[s] : cand;
         }
-        {   // the replicated column 0 (a candidate only while j0 == 0)
+        if constexpr (t == 0) {
+            // the replicated column 0 can only be the pivot column of round 0: afterwards it has been passed (j0 >= 1),
+            // or -- if round 0 found no column at all -- nothing changes any more and it stays below the tolerance
             T cm = num<T>::abs(nb0[t]);
 #pragma unroll
             for (int r = t + 1; r < K; ++r) cm = num<T>::max(cm, num<T>::abs(nb0[r]));
-            cand = ((cm > tol) && (j0 == 0)) ? 0 : cand;
+            cand = (cm > tol) ? 0 : cand;
         }
         int jmin = min(cand, dpp_mov<0xB1>(cand));
         if constexpr (LN >= 4) jmin = min(jmin, dpp_mov<0x4E>(jmin));
@@ -537,7 +539,8 @@ __device__ __forceinline__ void rref_apply_quad_inl(T (&nb0)[K], T (&nb)[split_s
             T v = w[0] * nb[0][r];
 #pragma unroll
             for (int s = 1; s < S; ++s) v = num<T>::fma(w[s], nb[s][r], v);
-            f[r] = num<T>::fma(w0, nb0[r], qsum<LN>(v));
+            if constexpr (t == 0) f[r] = num<T>::fma(w0, nb0[r], qsum<LN>(v));
+            else f[r] = qsum<LN>(v);                      // jmin >= 1 from round 1 on
         }
         // ---- pivot row: first arg-max of |f| over rows t..K-1 (np.argmax semantics in the reference's row order)
         ATACOM_MARK("R_argmax");
@@ -583,7 +586,9 @@ __device__ __forceinline__ void rref_apply_quad_inl(T (&nb0)[K], T (&nb)[split_s
         };
 #pragma unroll
         for (int s = 0; s < S; ++s) update(nb[s], col[s] >= jmin);
-        update(nb0, jmin == 0);
+        // column 0 lies left of every later pivot column, and the contraction below reads it only in a row whose pivot
+        // column it is -- row 0 of round 0, which no later row swap (rows >= t >= 1) touches: rounds >= 1 leave it alone
+        if constexpr (t == 0) update(nb0, jmin == 0);
         jrow[t] = jmin;
         j0 = found ? jmin + 1 : j0;
     });

@@ -28,3 +28,29 @@ for name in sys.argv[1:] or ['iiwa']:
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / n * 1e3
         print('%s %s lanes=%d B=%d step %.1f us -> %.3g env-steps/s  logs %s' % (os.path.basename(tag), name, lanes, B, us, B / us * 1e6, env.get_constraints_logs()), flush=True)
+        if os.environ.get('MB_ROLLOUT'):
+            # the T-step kernels: plain rollout and (planar / iiwa) the rollout with the actor MLP inside
+            from rl_on_manifold_amd import MlpPolicy
+            T = 40
+            acts = torch.rand((T, B, k), device=dev, generator=gen) * 2 - 1
+            out = env.rollout(acts)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(5): env.rollout(acts, out=out)
+            e1.record(); torch.cuda.synchronize()
+            ur = e0.elapsed_time(e1) / (5 * T) * 1e3
+            msg = 'rollout %.1f us/step' % ur
+            if name != 'circle':
+                g2 = torch.Generator(device='cpu'); g2.manual_seed(0)
+                D = env.obs_dim
+                W = [torch.randn((64, D), generator=g2) * 0.1, torch.zeros(64), torch.randn((64, 64), generator=g2) * 0.1,
+                     torch.zeros(64), torch.randn((k, 64), generator=g2) * 0.1, torch.zeros(k)]
+                pol = MlpPolicy(*[w.to(dev) for w in W], std=torch.ones(k, device=dev))
+                eps = torch.randn((T, B, k), device=dev, generator=gen)
+                env.rollout_policy(pol, T, noise=eps)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(5): env.rollout_policy(pol, T, noise=eps)
+                e1.record(); torch.cuda.synchronize()
+                msg += ', policy rollout %.1f us/step' % (e0.elapsed_time(e1) / (5 * T) * 1e3)
+            print('    ' + msg, flush=True)
