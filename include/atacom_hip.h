@@ -181,6 +181,10 @@ int atacom_rollout_packed(atacom_handle* h, int32_t n_steps, const void* d_actio
  * (env, step) logged since the last clear.  Synchronises `stream`. */
 int atacom_get_stats(atacom_handle* h, double out[3], int32_t clear, void* stream);
 
+/* The kernel mapping this handle runs: lanes per environment (1, 2, 4 or 8) -- cfg.lanes_per_env, or what the library
+ * chose for lanes_per_env = 0.  (The policy-rollout kernels run at most 4 lanes per environment whatever this says.) */
+int atacom_get_lanes(const atacom_handle* h, int32_t* out_lanes);
+
 /* Parity injection / checkpointing: d_state [batch, state_dim]. */
 int atacom_get_state(atacom_handle* h, void* d_state, void* stream);
 int atacom_set_state(atacom_handle* h, const void* d_state, void* stream);

@@ -17,7 +17,7 @@ MAX_C, MAX_Q = 12, 6
 EXPORTS = ['atacom_rollout_mlp', 'atacom_rollout_packed', 'atacom_get_aux_state', 'atacom_set_aux_state',
            'atacom_inverse_dynamics', 'atacom_forward_dynamics', 'atacom_default_config', 'atacom_get_dims', 'atacom_create', 'atacom_destroy', 'atacom_reset',
            'atacom_step', 'atacom_rollout', 'atacom_get_stats', 'atacom_get_state', 'atacom_set_state',
-           'atacom_nullspace', 'atacom_constraint_terms', 'atacom_last_error', 'atacom_version']
+           'atacom_nullspace', 'atacom_constraint_terms', 'atacom_last_error', 'atacom_version', 'atacom_get_lanes']
 
 
 class AtacomConfig(C.Structure):
@@ -84,6 +84,7 @@ def load():
     lib.atacom_rollout_mlp.argtypes = [vp, i32, C.POINTER(AtacomMlp), vp, vp, vp, vp, vp, u8p, u8p, vp]
     lib.atacom_rollout_packed.argtypes = [vp, i32, vp, C.POINTER(AtacomMlp), vp, vp, i32, vp]
     lib.atacom_get_stats.argtypes = [vp, C.POINTER(C.c_double * 3), i32, vp]
+    lib.atacom_get_lanes.argtypes = [vp, C.POINTER(i32)]
     lib.atacom_get_state.argtypes = [vp, vp, vp]
     lib.atacom_set_state.argtypes = [vp, vp, vp]
     lib.atacom_get_aux_state.argtypes = [vp, vp, vp]

@@ -357,6 +357,12 @@ int atacom_rollout_packed(atacom_handle* h, int32_t n_steps, const void* d_actio
     return ATACOM_OK;
 }
 
+int atacom_get_lanes(const atacom_handle* h, int32_t* out_lanes) {
+    if (!h || !out_lanes) return fail(ATACOM_E_INVALID, "atacom_get_lanes: null argument");
+    *out_lanes = pick_lanes(h->cfg);
+    return ATACOM_OK;
+}
+
 int atacom_get_stats(atacom_handle* h, double out[3], int32_t clear, void* stream) {
     if (!h || !out) return fail(ATACOM_E_INVALID, "atacom_get_stats: null argument");
     ON_DEVICE(h);

@@ -241,6 +241,13 @@ class BatchedAtacomEnv:
                 'next_obs': rec[..., D + k + 1:2 * D + k + 1], 'absorbing': rec[..., 2 * D + k + 1] > 0.5,
                 'last': rec[..., 2 * D + k + 2] > 0.5}
 
+    @property
+    def lanes_per_env(self):
+        """The kernel mapping this handle runs: lanes per environment (what the library chose when 0 was requested)."""
+        out = C.c_int32(0)
+        _lib.check(self._lib.atacom_get_lanes(self._h, C.byref(out)))
+        return int(out.value)
+
     def get_constraints_logs(self, clear=True):
         res = (C.c_double * 3)()
         _lib.check(self._lib.atacom_get_stats(self._h, C.byref(res), int(clear), self._stream()))
