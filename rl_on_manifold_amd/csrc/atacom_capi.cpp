@@ -106,8 +106,8 @@ struct atacom_handle {
     atacom_config cfg;
     int device;
     const atacom::EnvOps* ops;
-    void* f;        // float planes [n_planes][batch]
-    int* ip;        // int planes [n_iplanes][batch]
+    void* f;        // float fields, groups of four: [n_planes / 4][batch][4]  (atacom_kernels.h: Planes)
+    int* ip;        // int fields: [batch][4]
     double* partial_dev;
     double* partial_host;
 };

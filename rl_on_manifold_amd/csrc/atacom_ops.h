@@ -8,7 +8,8 @@
 namespace atacom {
 
 struct EnvOps {
-    int n_planes, n_iplanes, state_dim, init_dim, obs_dim, nq, nf, ng, nk;
+    int n_planes, n_iplanes;     // per-environment allocation: values in the float buffer (hot + cold groups of four), ints
+    int state_dim, init_dim, obs_dim, nq, nf, ng, nk;
     size_t elem;
     // lanes = 1, 2, 4 or 8 (lanes per environment)
     void (*step)(const atacom_config&, int lanes, void* f, int* ip, const void* act, void* obs, void* rew,

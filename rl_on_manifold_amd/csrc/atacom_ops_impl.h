@@ -39,7 +39,7 @@ static inline int nblk(int n, int per) { return (n + per - 1) / per; }
 template <typename T, typename E>
 struct Ops {
     using L = Planes<E>;
-    // kernel variants: LANES in {1, 2, 4} x HOLD in {true, false}
+    // kernel variants: LANES in {1, 2, 4, 8} x HOLD in {true, false}
     template <int LANES, bool HOLD>
     static void launch_step(const atacom_config& c, void* f, int* ip, const void* act, void* obs, void* rew,
                             uint8_t* ab, uint8_t* last, hipStream_t s) {

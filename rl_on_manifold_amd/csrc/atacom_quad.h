@@ -4,8 +4,8 @@
 // Why (measured in profiles/): a wave64 vector instruction occupies its SIMD for 4 clocks and a
 // lone wave already saturates it, so the step time is (vector instructions per wave) x ~5 clk.  With one environment
 // per lane the headline batch of 8192 environments is 128 wavefronts on 1024 SIMDs, each running the whole 23 k-
-// instruction step (53 us).  Splitting every environment over the 4 lanes of a DPP quad puts 512 waves to work at
-// ~0.55x the instructions per wave (28 us); beyond 16384 environments (1024 waves) the narrower mappings win again
+// instruction step (51 us).  Splitting every environment over the 4 lanes of a DPP quad puts 512 waves to work at
+// ~0.5x the instructions per wave (26 us); beyond 16384 environments (1024 waves) the narrower mappings win again
 // because their total instruction count is lower.
 //
 // Data distribution inside a quad (lq = lane & 3) -- "column 0 replicated", see split_slots below:
