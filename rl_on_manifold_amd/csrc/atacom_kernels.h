@@ -620,6 +620,9 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     const int b = gt / LANES;                  // whole quads leave together (BLOCK % LANES == 0)
     const int lq = gt % LANES;
     if (b >= B) return;
+#ifdef ATACOM_TIMESTAMPS        // tuning build only (tests/gpu_phase_probe.py): 100 MHz wall-clock stamps per phase
+    const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
+#endif
     EnvState<T, E> st;
     load_state<T, E>(f, ip, B, b, st);
     // the statistics accumulators are read up front with the rest of the state: a read-modify-write at the end
@@ -632,8 +635,17 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     for (int k = 0; k < E::NK; ++k) act[k] = action[(size_t)b * E::NK + k];
     if constexpr (DYN) load_aux<T, E>(f, B, b, st);
     StepOut<T> out;
+#ifdef ATACOM_TIMESTAMPS
+    // the stamp must not float above the loads' completion: make it depend on a loaded value
+    unsigned long long ts1;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1) : "v"(st.q[0]) : "memory");
+#endif
     env_step<T, E, LANES, HOLD, DYN>(P, st, act, out, lq);
     ATACOM_MARK("STORE");
+#ifdef ATACOM_TIMESTAMPS
+    unsigned long long ts2;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts2) : "v"(out.reward) : "memory");
+#endif
     if (lq != 0) return;                       // the four lanes hold identical results; lane 0 writes
     write_obs<T, E>(P, st, obs + (size_t)b * E::OBS);
     reward[b] = out.reward;
@@ -646,6 +658,14 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     if (P.auto_reset && out.last) reset_env<T, E>(P, f, ip, B, b, st);
     store_state<T, E>(f, ip, B, b, st);
     if constexpr (DYN) store_aux<T, E>(f, B, b, st);
+#ifdef ATACOM_TIMESTAMPS
+    {   // overwrite the first observation entries with the stamps (low 32 bits, 10 ns ticks); ts3 after the stores landed
+        unsigned long long ts3;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts3) :: "memory");
+        unsigned int* o = reinterpret_cast<unsigned int*>(obs + (size_t)b * E::OBS);
+        o[0] = (unsigned int)ts0; o[1] = (unsigned int)ts1; o[2] = (unsigned int)ts2; o[3] = (unsigned int)ts3;
+    }
+#endif
 }
 
 template <typename T, typename E, int LANES, bool HOLD, bool DYN = false>

@@ -1,0 +1,34 @@
+"""Kernel-tuning helper (not a pytest file): where do the ~26 us of one atacom_step launch go?
+
+Needs a library built with -DATACOM_TIMESTAMPS (ATACOM_HIPCC_FLAGS=-DATACOM_TIMESTAMPS ATACOM_LIB_OUT=... python -m
+rl_on_manifold_amd.build), whose k_step overwrites obs[:, 0:4] with four 100 MHz wall-clock stamps per environment:
+wave start, state loaded, sub-steps done, stores landed.  Usage: ATACOM_LIB=<that .so> python tests/gpu_phase_probe.py [lanes]
+"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, '.')
+from rl_on_manifold_amd import BatchedAtacomEnv
+
+lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+B = int(os.environ.get('MB_BATCH', 8192))
+env = BatchedAtacomEnv('iiwa', B, device='cuda:0', dtype=torch.float32, lanes_per_env=lanes)
+a = torch.zeros((B, 5), device='cuda:0')
+for _ in range(20):
+    env.step_into(a, env._obs, env._reward, env._absorbing, env._last)
+torch.cuda.synchronize()
+rows = []
+for rep in range(10):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    env.step_into(a, env._obs, env._reward, env._absorbing, env._last)
+    e1.record(); torch.cuda.synchronize()
+    ts = env._obs[:, :4].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    t0 = ts[:, 0].min()
+    d = (ts - t0) * 0.01                                   # us since the first wave started
+    rows.append([e0.elapsed_time(e1) * 1e3, d[:, 0].max(), np.median(d[:, 1] - d[:, 0]), np.median(d[:, 2] - d[:, 1]),
+                 np.median(d[:, 3] - d[:, 2]), d[:, 3].max(), np.median(d[:, 3] - d[:, 0])])
+r = np.median(np.array(rows), 0)
+print('lanes %d, B %d: kernel (events) %.1f us | last wave starts %.2f us after the first | per wave (median): load %.2f, '
+      'compute %.2f, store %.2f, total %.2f | last store lands %.2f us after the first wave started'
+      % (lanes, B, r[0], r[1], r[2], r[3], r[4], r[6], r[5]))
