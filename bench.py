@@ -390,7 +390,7 @@ def main():
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': WORKLOAD[args.env] + ', batch %d per GPU' % B,
                        'batch_per_gpu': B, 'global_batch': B * world,
-                       'lanes_per_env_requested': int(env.cfg.lanes_per_env), 'lanes_per_env': env.lanes_per_env, 'substeps': int(env.cfg.substeps),
+                       'lanes_per_env_requested': int(env.cfg.lanes_per_env), 'lanes_per_env': env.lanes_per_env, 'rollout_lanes_per_env': env.rollout_lanes_per_env, 'substeps': int(env.cfg.substeps),
                        'horizon': int(env.cfg.horizon), 'path': 'atacom_step (1 launch / step) via C ABI',
                        'init': 'q_init + N(0, 0.05^2), one correction step, rejected unless all g < 0 and |f| < 1e-3 '
                                '(%.1f %% of draws rejected); puck uniform in the hit range' % (100 * rejected)

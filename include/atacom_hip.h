@@ -63,8 +63,8 @@ typedef struct atacom_config {
                             terminal observation, the next call starts from the reset state */
     int32_t lanes_per_env; /* kernel mapping: 1 = one env per lane, 2 = one env per lane pair, 4 = one env per DPP
                               quad, 8 = one env per 8 lanes (null-space solve split by column over the 2 / 4 / 8
-                              lanes), 0 = let the library choose per env / batch (iiwa: 8 up to 4096 envs, 4 up to
-                              16384, 2 up to 32768, 1 beyond).
+                              lanes), 0 = let the library choose per env / batch / kernel (iiwa: 8 up to 4096
+                              envs -- 8192 for the T-step kernels --, 4 up to 16384, 2 up to 32768, 1 beyond).
                               Results are the same algorithm either way (summation order differs). */
     double dt;           /* time_step */
     double rref_tol;     /* 0.05, atacom.py:128 */
@@ -181,9 +181,10 @@ int atacom_rollout_packed(atacom_handle* h, int32_t n_steps, const void* d_actio
  * (env, step) logged since the last clear.  Synchronises `stream`. */
 int atacom_get_stats(atacom_handle* h, double out[3], int32_t clear, void* stream);
 
-/* The kernel mapping this handle runs: lanes per environment (1, 2, 4 or 8) -- cfg.lanes_per_env, or what the library
- * chose for lanes_per_env = 0.  (The policy-rollout kernels run at most 4 lanes per environment whatever this says.) */
-int atacom_get_lanes(const atacom_handle* h, int32_t* out_lanes);
+/* The kernel mappings this handle runs: lanes per environment (1, 2, 4 or 8) of atacom_step and of the T-step kernels
+ * (atacom_rollout / _mlp / _packed) -- cfg.lanes_per_env, or what the library chose for lanes_per_env = 0 (the two may
+ * differ: the persistent state does not depend on the mapping).  Either output pointer may be NULL. */
+int atacom_get_lanes(const atacom_handle* h, int32_t* out_step_lanes, int32_t* out_rollout_lanes);
 
 /* Parity injection / checkpointing: d_state [batch, state_dim]. */
 int atacom_get_state(atacom_handle* h, void* d_state, void* stream);

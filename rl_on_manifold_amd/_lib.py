@@ -84,7 +84,7 @@ def load():
     lib.atacom_rollout_mlp.argtypes = [vp, i32, C.POINTER(AtacomMlp), vp, vp, vp, vp, vp, u8p, u8p, vp]
     lib.atacom_rollout_packed.argtypes = [vp, i32, vp, C.POINTER(AtacomMlp), vp, vp, i32, vp]
     lib.atacom_get_stats.argtypes = [vp, C.POINTER(C.c_double * 3), i32, vp]
-    lib.atacom_get_lanes.argtypes = [vp, C.POINTER(i32)]
+    lib.atacom_get_lanes.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     lib.atacom_get_state.argtypes = [vp, vp, vp]
     lib.atacom_set_state.argtypes = [vp, vp, vp]
     lib.atacom_get_aux_state.argtypes = [vp, vp, vp]

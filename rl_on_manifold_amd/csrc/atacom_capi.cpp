@@ -62,21 +62,24 @@ constexpr int kStatBlocks = 256;
 
 // kernel mapping policy for lanes_per_env = 0, from measurements on MI355X (profiles/r02_lanes_vs_batch.md): the fewer
 // lanes an environment is spread over, the fewer instructions in total but the more per wave; a mapping's step time is
-// flat while its waves still find a SIMD each (1024 SIMDs) and doubles beyond.  iiwa: 8 lanes up to 4096 envs, quad up to
-// 16384, pair up to 32768, lane beyond.  The 8-lane mapping has 13 % fewer instructions per wave than the quad and wins
-// wherever it leaves half of the chip idle like the quad does at twice the batch (26.1 vs 26.9 us per step at 4096 envs,
-// rollout kernel 23.1 vs 24.5 us per step, on every box tried).  At 8192 envs its 1024 waves occupy every CU, the shader
-// clock drops and the launch / load / store phase of a step grows by ~1 us: over nine boxes the two mappings tied on
-// average (27.2 us both; per box the 8-lane mapping ranged from 5 % faster to 4.5 % slower), so the quad -- same speed,
-// half the chip left free for a learner's kernels on another stream -- keeps that range.  planar (6 x 9): the quad is
-// the widest that pays.  The policy-rollout kernels (GEMM blocks of 16 environments = quads) have no 8-lane form and run
-// the quad mapping on the same handle -- the state layout does not depend on the mapping.
-int pick_lanes(const atacom_config& c) {
+// flat while its waves still find a SIMD each (1024 SIMDs) and doubles beyond.  iiwa: 8 lanes, then the quad up to 16384
+// envs, the pair up to 32768, the lane beyond.  The 8-lane mapping has 12 % fewer instructions per wave than the quad
+// and wins wherever it leaves half of the chip idle like the quad does at twice the batch (<= 4096 envs: 25.3 vs 26.0 us
+// per step, rollout kernels 22.0 vs 24.0 us per step, on every box tried).  At 8192 envs its 1024 waves occupy every CU:
+// the clock drops and the launch / load / store phase of a step grows, so single-step launches tie with the quad (27.2 us
+// both, mean of nine boxes; per box from 5 % faster to 4.5 % slower) and stay on the quad, while the T-step kernels --
+// state in registers, no per-step launch phase -- keep the 8-lane advantage (22.8 vs 23.9 us per step, with the policy
+// network 25.0 vs 26.5) and take it.  The state layout does not depend on the mapping, so the kernels of one handle may
+// differ.  planar (6 x 9): the quad is the widest that pays.
+enum { KIND_STEP = 0, KIND_ROLLOUT = 1 };
+int pick_lanes(const atacom_config& c, int kind) {
     if (c.lanes_per_env == 1 || c.lanes_per_env == 2 || c.lanes_per_env == 4 || c.lanes_per_env == 8)
         return c.lanes_per_env;
     if (c.dtype == ATACOM_F64) return 1;
-    if (c.env_id == ATACOM_ENV_IIWA)                                       // 26 / 27 / 37 / 53 us per step
-        return c.batch <= 4096 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));
+    if (c.env_id == ATACOM_ENV_IIWA) {
+        const int upto8 = (kind == KIND_ROLLOUT) ? 8192 : 4096;
+        return c.batch <= upto8 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));
+    }
     if (c.env_id == ATACOM_ENV_PLANAR)
         return c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1);
     return 1;                                                              // circle: launch-bound either way
@@ -285,10 +288,10 @@ int atacom_step(atacom_handle* h, const void* d_action, void* d_obs, void* d_rew
         return fail(ATACOM_E_INVALID, "atacom_step: d_action, d_obs, d_reward and d_absorbing are required");
     ON_DEVICE(h);
     if (h->cfg.dynamics_mode == 1)
-        atacom::ops_iiwa_dyn(h->cfg.dtype)->step(h->cfg, pick_lanes(h->cfg), h->f, h->ip, d_action, d_obs, d_reward,
+        atacom::ops_iiwa_dyn(h->cfg.dtype)->step(h->cfg, pick_lanes(h->cfg, KIND_STEP), h->f, h->ip, d_action, d_obs, d_reward,
                                                   d_absorbing, d_last, (hipStream_t)stream);
     else
-    h->ops->step(h->cfg, pick_lanes(h->cfg), h->f, h->ip, d_action, d_obs, d_reward, d_absorbing, d_last, (hipStream_t)stream);
+    h->ops->step(h->cfg, pick_lanes(h->cfg, KIND_STEP), h->f, h->ip, d_action, d_obs, d_reward, d_absorbing, d_last, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
 }
@@ -301,7 +304,7 @@ int atacom_rollout(atacom_handle* h, int32_t n_steps, const void* d_actions, voi
         return fail(ATACOM_E_INVALID, "atacom_rollout: all buffers except d_next_obs are required");
     ON_DEVICE(h);
     (h->cfg.dynamics_mode == 1 ? atacom::ops_iiwa_dyn(h->cfg.dtype)->rollout : h->ops->rollout)(
-        h->cfg, pick_lanes(h->cfg), n_steps, h->f, h->ip, d_actions, d_obs, d_next_obs, d_reward, d_absorbing, d_last,
+        h->cfg, pick_lanes(h->cfg, KIND_ROLLOUT), n_steps, h->f, h->ip, d_actions, d_obs, d_next_obs, d_reward, d_absorbing, d_last,
         nullptr, 0, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
@@ -319,7 +322,7 @@ int atacom_rollout_mlp(atacom_handle* h, int32_t n_steps, const atacom_mlp* net,
     if (h->cfg.dynamics_mode == 1)
         return fail(ATACOM_E_UNSUPPORTED, "the policy rollout kernels have no rigid-body form (dynamics_mode 1)");
     ON_DEVICE(h);
-    const int rc = h->ops->rollout_mlp(h->cfg, pick_lanes(h->cfg), n_steps, *net, h->f, h->ip, d_noise, d_obs,
+    const int rc = h->ops->rollout_mlp(h->cfg, pick_lanes(h->cfg, KIND_ROLLOUT), n_steps, *net, h->f, h->ip, d_noise, d_obs,
                                        d_next_obs, d_actions, d_reward, d_absorbing, d_last, nullptr, 0,
                                        (hipStream_t)stream);
     if (rc != ATACOM_OK)
@@ -342,12 +345,12 @@ int atacom_rollout_packed(atacom_handle* h, int32_t n_steps, const void* d_actio
         return fail(ATACOM_E_UNSUPPORTED, "the policy rollout kernels have no rigid-body form (dynamics_mode 1)");
     if (d_actions) {
         (h->cfg.dynamics_mode == 1 ? atacom::ops_iiwa_dyn(h->cfg.dtype)->rollout : h->ops->rollout)(
-            h->cfg, pick_lanes(h->cfg), n_steps, h->f, h->ip, d_actions, nullptr, nullptr, nullptr, nullptr, nullptr,
+            h->cfg, pick_lanes(h->cfg, KIND_ROLLOUT), n_steps, h->f, h->ip, d_actions, nullptr, nullptr, nullptr, nullptr, nullptr,
             d_records, record_batch_stride, (hipStream_t)stream);
     } else {
         const int vrc = check_mlp(h, net, "atacom_rollout_packed");
         if (vrc != ATACOM_OK) return vrc;
-        const int rc = h->ops->rollout_mlp(h->cfg, pick_lanes(h->cfg), n_steps, *net, h->f, h->ip, d_noise, nullptr, nullptr,
+        const int rc = h->ops->rollout_mlp(h->cfg, pick_lanes(h->cfg, KIND_ROLLOUT), n_steps, *net, h->f, h->ip, d_noise, nullptr, nullptr,
                                            nullptr, nullptr, nullptr, nullptr, d_records, record_batch_stride,
                                            (hipStream_t)stream);
         if (rc != ATACOM_OK)
@@ -357,9 +360,10 @@ int atacom_rollout_packed(atacom_handle* h, int32_t n_steps, const void* d_actio
     return ATACOM_OK;
 }
 
-int atacom_get_lanes(const atacom_handle* h, int32_t* out_lanes) {
-    if (!h || !out_lanes) return fail(ATACOM_E_INVALID, "atacom_get_lanes: null argument");
-    *out_lanes = pick_lanes(h->cfg);
+int atacom_get_lanes(const atacom_handle* h, int32_t* out_step_lanes, int32_t* out_rollout_lanes) {
+    if (!h) return fail(ATACOM_E_INVALID, "atacom_get_lanes: null handle");
+    if (out_step_lanes) *out_step_lanes = pick_lanes(h->cfg, KIND_STEP);
+    if (out_rollout_lanes) *out_rollout_lanes = pick_lanes(h->cfg, KIND_ROLLOUT);
     return ATACOM_OK;
 }
 

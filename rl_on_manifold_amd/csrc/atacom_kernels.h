@@ -685,13 +685,23 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
     load_state<T, E>(f, ip, B, b, st);
     if constexpr (DYN) load_aux<T, E>(f, B, b, st);
     T ssum = T(0), scmax = pl<E>(f, L::SCMAX, B, b), sdq = pl<E>(f, L::SDQMAX, B, b);
+    // the actions of step t + 1 are fetched while step t computes: a load at the top of the step it feeds would expose
+    // one HBM round trip (~1 us) per step to a wave that has nothing else to run
+    T act_next[E::NK];
+#pragma unroll
+    for (int k = 0; k < E::NK; ++k) act_next[k] = (n_steps > 0) ? actions[(size_t)b * E::NK + k] : T(0);
 #pragma unroll 1
     for (int t = 0; t < n_steps; ++t) {
         const size_t row = (size_t)t * B + b;
         T* const rrow = rec ? rec + ((size_t)t * rec_ld + b) * R::F : nullptr;     // packed record of (t, b)
         T act[E::NK];
 #pragma unroll
-        for (int k = 0; k < E::NK; ++k) act[k] = actions[row * E::NK + k];
+        for (int k = 0; k < E::NK; ++k) act[k] = act_next[k];
+        {
+            const size_t nrow = (size_t)((t + 1 < n_steps) ? t + 1 : t) * B + b;    // last step: a harmless re-read
+#pragma unroll
+            for (int k = 0; k < E::NK; ++k) act_next[k] = actions[nrow * E::NK + k];
+        }
         if (lq == 0) {
             if (rec) {
                 write_obs<T, E>(P, st, rrow + R::OBS);
@@ -739,7 +749,9 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
 template <typename T, typename E, int LANES, int H>
 struct MlpPath {
     static constexpr bool MFMA = std::is_same<T, float>::value && H == 64 && E::OBS <= 32 && E::NK <= 8;
-    static constexpr int NB = WAVE / (16 * LANES);        // blocks of 16 environments per wavefront
+    // blocks of 16 environments per wavefront; with 8 lanes per environment a wave holds 8 environments: ONE block whose
+    // columns 8..15 are padding (zero observations in, outputs never read -- GEMM columns do not mix)
+    static constexpr int NB = (16 * LANES >= WAVE) ? 1 : WAVE / (16 * LANES);
     using LM = MlpLdsM<(E::OBS <= 32 ? E::OBS : 32), 64, (E::NK <= 8 ? E::NK : 8)>;
     // 256-thread workgroups in both mappings: the staged weights (30 KB per network) are shared by 4 wavefronts; with
     // one wave per workgroup the LDS footprint capped the lane mapping at 2 waves per CU (measured: 2x the time)
@@ -757,6 +769,7 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
     using L = Planes<E>;
     using R = Record<E>;
     constexpr bool MFMA = MlpPath<T, E, LANES, H>::MFMA;
+    static_assert(LANES <= 4 || MFMA, "8 lanes per environment: matrix-core form only");
     constexpr int THREADS = MlpPath<T, E, LANES, H>::THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* lds = reinterpret_cast<T*>(smem);
@@ -783,6 +796,11 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
 #pragma unroll 1
     for (int t = 0; t < n_steps; ++t) {
         const size_t row = (size_t)t * B + b;
+        // the step's exploration noise is requested before the network runs (the wave fences of the LDS staging would
+        // otherwise pin the loads behind it, one exposed HBM round trip per step)
+        T eps[E::NK];
+#pragma unroll
+        for (int k = 0; k < E::NK; ++k) eps[k] = noise ? noise[row * E::NK + k] : T(0);
         T o[E::OBS];
         write_obs<T, E>(P, st, o);
         T act[E::NK], sig[E::NK];
@@ -808,8 +826,7 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
         }
 #pragma unroll
         for (int k = 0; k < E::NK; ++k) {
-            const T eps = noise ? noise[row * E::NK + k] : T(0);
-            act[k] = num<T>::fma(sig[k], eps, act[k]);
+            act[k] = num<T>::fma(sig[k], eps[k], act[k]);
             if (net.squash) act[k] = num<T>::tanh(act[k]);
         }
         T* const rrow = rec ? rec + ((size_t)t * rec_ld + b) * R::F : nullptr;

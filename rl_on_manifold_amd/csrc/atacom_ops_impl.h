@@ -116,7 +116,16 @@ struct Ops {
         a.log_std_min = (T)net.log_std_min; a.log_std_max = (T)net.log_std_max; a.squash = net.squash;
         a.n_in = net.n_in; a.n_out = net.n_out; a.activation = net.activation;
         if constexpr (E::ID != 0) {
-            if (lanes >= 4) {          // the policy kernels have no 8-lane form (their GEMM blocks are 16 envs = quads)
+            if constexpr (MlpPath<T, E, 8, 64>::MFMA) {
+                // 8 lanes per environment: matrix-core form only (a wave = one GEMM block of 16 columns, 8 of them
+                // environments); the float64 parity build runs the quad form instead
+                if (lanes == 8) {
+                    if (c.hold_q) launch_mlp<8, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
+                    else launch_mlp<8, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
+                    return ATACOM_OK;
+                }
+            }
+            if (lanes >= 4) {
                 if (c.hold_q) launch_mlp<4, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
                 else launch_mlp<4, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
             } else if (lanes == 2) {

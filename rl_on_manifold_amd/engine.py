@@ -241,12 +241,20 @@ class BatchedAtacomEnv:
                 'next_obs': rec[..., D + k + 1:2 * D + k + 1], 'absorbing': rec[..., 2 * D + k + 1] > 0.5,
                 'last': rec[..., 2 * D + k + 2] > 0.5}
 
+    def _lanes(self):
+        a, b = C.c_int32(0), C.c_int32(0)
+        _lib.check(self._lib.atacom_get_lanes(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     @property
     def lanes_per_env(self):
-        """The kernel mapping this handle runs: lanes per environment (what the library chose when 0 was requested)."""
-        out = C.c_int32(0)
-        _lib.check(self._lib.atacom_get_lanes(self._h, C.byref(out)))
-        return int(out.value)
+        """The kernel mapping step() runs: lanes per environment (what the library chose when 0 was requested)."""
+        return self._lanes()[0]
+
+    @property
+    def rollout_lanes_per_env(self):
+        """The kernel mapping of rollout() / rollout_policy() / rollout_packed() (may differ from step()'s)."""
+        return self._lanes()[1]
 
     def get_constraints_logs(self, clear=True):
         res = (C.c_double * 3)()

@@ -325,7 +325,7 @@ def _policy_pair(golden, key, std=0.5, activation='relu'):
     return dev, ora
 
 
-@pytest.mark.parametrize('lanes', [1, 2, 4])
+@pytest.mark.parametrize('lanes', [1, 2, 4, 8])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 @pytest.mark.parametrize('name,key', [('iiwa', 'ppo_iiwa'), ('planar', 'sac_planar')])
 def test_policy_rollout_against_oracle(golden, name, key, dt, lanes):
@@ -364,7 +364,7 @@ def test_policy_rollout_against_oracle(golden, name, key, dt, lanes):
         print(rec.finish('policy %s lanes %d' % (name, lanes)))
 
 
-@pytest.mark.parametrize('lanes', [1, 2, 4])
+@pytest.mark.parametrize('lanes', [1, 2, 4, 8])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 def test_sac_style_policy_rollout_against_oracle(golden, dt, lanes):
     """The reference's default agent is SAC (examples/iiwa_air_hockey_exp.py:345): mean and log-sigma networks
@@ -416,10 +416,11 @@ def test_policy_rollout_multi_step_consistency(golden):
     """T-step policy rollout == feeding the actions it drew to the plain rollout kernel; deterministic without noise."""
     B, T = 192, 10
     dev, _ = _policy_pair(golden, 'ppo_iiwa')
-    # the policy kernels run the quad mapping (GEMM blocks of 16 environments); the plain rollout they are compared
-    # with must use the same mapping for the two to agree to rounding (the automatic choice at this batch is 8 lanes)
-    e1 = _env('iiwa', B, 'f32', auto_reset=True, horizon=4, lanes_per_env=4)
-    e2 = _env('iiwa', B, 'f32', auto_reset=True, horizon=4, lanes_per_env=4)
+    # both T-step kernels run the same mapping under the automatic choice (8 lanes at this batch), which the two need
+    # to agree to rounding
+    e1 = _env('iiwa', B, 'f32', auto_reset=True, horizon=4)
+    e2 = _env('iiwa', B, 'f32', auto_reset=True, horizon=4)
+    assert e1.rollout_lanes_per_env == 8
     gen = torch.Generator(device=DEV); gen.manual_seed(1)
     eps = torch.randn((T, B, 5), device=DEV, generator=gen)
     o1 = e1.rollout_policy(dev, T, noise=eps)
@@ -685,6 +686,10 @@ def test_host_side_error_paths_and_multiple_handles():
                            ('planar', 8192, 4), ('planar', 65536, 1), ('circle', 4096, 1)):
         assert BatchedAtacomEnv(name, B, device=DEV).lanes_per_env == lanes, (name, B)
     assert BatchedAtacomEnv('iiwa', 8192, device=DEV, lanes_per_env=8).lanes_per_env == 8
+    e = BatchedAtacomEnv('iiwa', 8192, device=DEV)            # the T-step kernels keep 8 lanes up to 8192 environments
+    assert (e.lanes_per_env, e.rollout_lanes_per_env) == (4, 8)
+    e = BatchedAtacomEnv('iiwa', 16384, device=DEV)
+    assert (e.lanes_per_env, e.rollout_lanes_per_env) == (4, 4)
     assert BatchedAtacomEnv('iiwa', 64, device=DEV, dtype=torch.float64).lanes_per_env == 1
     a = torch.full((96, 3), 0.3, device=DEV)
     side = torch.cuda.Stream(device=DEV)
