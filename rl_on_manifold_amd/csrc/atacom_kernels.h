@@ -285,7 +285,7 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
 // LANES = 1: one environment per lane (atacom_linalg.h).  LANES = 4: one environment per DPP quad -- the
 // null-space solve is column-split over the quad (atacom_quad.h), everything else is computed redundantly
 // (and bitwise identically) by the four lanes; `lq` is the lane's index in its quad.
-template <typename T, typename E, int LANES, bool HOLD, bool DYN = false>
+template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, bool HOIST_G0 = true>
 __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st, const T (&act)[E::NK],
                                          StepOut<T>& out, const int lq) {
     constexpr int NQ = E::NQ, NF = E::NF, NG = E::NG, NC = E::NC, NN = E::NN, NK = E::NK;
@@ -327,9 +327,9 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
     T m0x = T(0), m0y = T(0);   // mallet position at the start of the env step
     T A[NC][NQ], yb[NC];       // yb = psi + Kc c0: the slack-independent part of the right-hand side (one value
                                // per row carried over the sub-steps instead of two)
-    // hoist of the sub-step-invariant first reflector (see prepare): group mappings, ATACOM mode, held q / dq, and an
+    // hoist of the sub-step-invariant first reflector (see prepare): every mapping, ATACOM mode, held q / dq, and an
     // equality row on top of J_c (iiwa; the planar and circle J_c start with a slack-carrying row)
-    constexpr bool G0PRE = HOLD && LANES > 1 && E::MODE == 0 && NF > 0 && NQ > 1;
+    constexpr bool G0PRE = HOIST_G0 && HOLD && E::MODE == 0 && NF > 0 && NQ > 1;
     T g0_d = T(0), g0_tau = T(0);
     constexpr int LGC = LANES > 1 ? LANES : 4;                  // lanes per environment of the group solver
     constexpr int SQ = split_slots(NN, LGC);
@@ -443,7 +443,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 else return T(0);
             };
             auto yget = [&](auto rc) -> T { return y[decltype(rc)::value]; };
-            bidiag_solve_null<T, NC, NN>(aget, yget, x, nb);        // atacom.py:127 (pinv_null)
+            bidiag_solve_null<T, NC, NN, G0PRE, NQ>(aget, yget, x, nb, g0_d, g0_tau);        // atacom.py:127 (pinv_null)
             if (E::MODE == 1) {
                 // error_correction_wrapper.py:127-130: [alpha; 0] - Jc^+ (Kc c), the null basis is not used
 #pragma unroll
@@ -839,7 +839,10 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
             for (int k = 0; k < E::NK; ++k) ad[k] = act[k];
         }
         StepOut<T> out;
-        env_step<T, E, LANES, HOLD>(P, st, act, out, lq);
+        // (one environment per lane with the network's four GEMM blocks live is the one kernel at the edge of the register
+        // file: with the G(0) hoist its spills move INTO the sub-step loop -- 59.6 -> 79.5 us per step, measured -- so it
+        // keeps the un-hoisted solver)
+        env_step<T, E, LANES, HOLD, false, (LANES > 1)>(P, st, act, out, lq);
         if (lq == 0 && valid) {
             if (rec) {
                 write_obs<T, E>(P, st, rrow + R::NOBS);

@@ -179,8 +179,13 @@ __device__ __forceinline__ void bidiag_forward_solve(const T (&d)[M], const T (&
 // scipy.linalg.svd(A, full_matrices=True)[2][M:].T up to rounding.
 // Every per-row quantity is kept as ROW PAIRS (vec2: rows 2p, 2p+1 of one column) and the K null vectors + x as
 // pairs over the vector index, so all multiply-adds are packed (v_pk_fma_f32) by construction.
-template <typename T, int M, int N, typename AF, typename YF>
-__device__ __forceinline__ void bidiag_solve_null(AF&& aget, YF&& yget, T (&x)[N], T (&nb)[N][N - M]) {
+// PRE0 (see the lane-group solver in atacom_quad.h for the idea): the caller has generated the first right reflector
+// G(0) and applied it to the rows below -- it is the same for all physics sub-steps of a step when row 0 is a slack-free
+// equality row and q, dq are held.  Row 0 of the matrix handed over holds the reflector vector (columns 1 .. NV0-1;
+// structurally zero from NV0 on), pre_d0 / pre_tau0 are its beta / tau.
+template <typename T, int M, int N, bool PRE0 = false, int NV0 = N, typename AF, typename YF>
+__device__ __forceinline__ void bidiag_solve_null(AF&& aget, YF&& yget, T (&x)[N], T (&nb)[N][N - M],
+                                                  const T pre_d0 = T(0), const T pre_tau0 = T(0)) {
     constexpr int K = N - M;
     constexpr int MP = (M + 1) / 2;          // row pairs (a zero row pads an odd M: it is a fixed point of every step)
     constexpr int KP = (K + 2) / 2;          // pairs over [nb_0 .. nb_{K-1}, x]
@@ -206,18 +211,24 @@ __device__ __forceinline__ void bidiag_solve_null(AF&& aget, YF&& yget, T (&x)[N
         constexpr int pi = i / 2, hi = i % 2;      // row i is half hi of row pair pi
         __builtin_amdgcn_sched_barrier(0);         // do not overlap reflector steps: keeps the live set near M*N
         // ---- right reflector G(i): annihilate A[i][i+1..N); v (v[i] = 1 implicit) stays in row i
+        constexpr bool pre = PRE0 && i == 0;       // G(0) came with the matrix
+        T v[N];
+        T tp = pre_tau0;
+        if constexpr (pre) { d[0] = pre_d0; taup[0] = pre_tau0; }
+        else {
         T ss = T(0);
 #pragma unroll
         for (int c = i + 1; c < N; ++c) ss = num<T>::fma(a2[pi][c][hi], a2[pi][c][hi], ss);
-        T beta, tp;
+        T beta;
         const T sc = larfg_scale(a2[pi][i][hi], ss, beta, tp);
         d[i] = beta;
         taup[i] = tp;
-        T v[N];
 #pragma unroll
         for (int c = i + 1; c < N; ++c) { v[c] = a2[pi][c][hi] * sc; a2[pi][c][hi] = v[c]; }
+        }
         if constexpr (i < M - 1) {
             constexpr int p0 = (i + 1) / 2;        // first row pair holding a row > i
+            if constexpr (!pre) {
 #pragma unroll
             for (int p = p0; p < MP; ++p) {
                 V2 w = a2[p][i];
@@ -229,6 +240,7 @@ __device__ __forceinline__ void bidiag_solve_null(AF&& aget, YF&& yget, T (&x)[N
 #pragma unroll
                 for (int c = i + 1; c < N; ++c) a2[p][c] = fma2(-w, splat2(v[c]), a2[p][c]);
             }
+            }   // !pre
             // ---- left reflector H(i): annihilate A[i+2..M)[i]; u over the pairs p0..: 0 for rows <= i, 1 at row
             // i+1, scaled column entries below (not kept: Q is applied to y on the fly)
             V2 sq = splat2(T(0));
@@ -284,18 +296,19 @@ __device__ __forceinline__ void bidiag_solve_null(AF&& aget, YF&& yget, T (&x)[N
     static_for<0, M>([&](auto kc) {
         constexpr int i = M - 1 - decltype(kc)::value;
         __builtin_amdgcn_sched_barrier(0);
+        constexpr int CE = (PRE0 && i == 0) ? NV0 : N;      // the hoisted G(0) is zero from column NV0 on
         T v[N];
 #pragma unroll
-        for (int c = i + 1; c < N; ++c) v[c] = a2[i / 2][c][i % 2];
+        for (int c = i + 1; c < CE; ++c) v[c] = a2[i / 2][c][i % 2];
 #pragma unroll
         for (int j = 0; j < KP; ++j) {
             V2 w = nx[i][j];
 #pragma unroll
-            for (int c = i + 1; c < N; ++c) w = fma2(splat2(v[c]), nx[c][j], w);
+            for (int c = i + 1; c < CE; ++c) w = fma2(splat2(v[c]), nx[c][j], w);
             w *= splat2(taup[i]);
             nx[i][j] -= w;
 #pragma unroll
-            for (int c = i + 1; c < N; ++c) nx[c][j] = fma2(-w, splat2(v[c]), nx[c][j]);
+            for (int c = i + 1; c < CE; ++c) nx[c][j] = fma2(-w, splat2(v[c]), nx[c][j]);
         }
     });
 #pragma unroll
