@@ -197,6 +197,24 @@ def test_env_step_teacher_forced_against_oracle(name, dt, lanes):
     assert np.allclose(c_dev, c_or, atol=1e-8 if dt == 'f64' else 2e-3)
 
 
+@pytest.mark.parametrize('lanes', [1, 2, 4])
+def test_circle_hold_flag_is_a_no_op(lanes):
+    """CircularMotion has ONE physics sub-step per env step, so hold_q cannot change anything -- but hold_q = 1 selects
+    the kernels with the first right reflector hoisted out of the (one-trip) sub-step loop (row 0 of the circle's J_c is
+    its slack-free equality row), at the smallest shape the solvers see (2 x 3)."""
+    B, T = 256, 30
+    rng = np.random.default_rng(5)
+    for dt, tol in (('f64', 1e-12), ('f32', 2e-5)):
+        e0 = _env('circle', B, dt, lanes_per_env=lanes, hold_q=False)
+        e1 = _env('circle', B, dt, lanes_per_env=lanes, hold_q=True)
+        for t in range(T):
+            a = rng.uniform(-1.2, 1.2, (B, 1))
+            e1.set_state(e0.get_state())
+            o0, r0, _, _ = e0.step(a)
+            o1, r1, _, _ = e1.step(a)
+            assert (o0 - o1).abs().max() < tol and (r0 - r1).abs().max() < tol, (dt, t)
+
+
 @pytest.mark.parametrize('lanes', [1, 2, 4, 8])
 @pytest.mark.parametrize('name', ['planar', 'iiwa'])
 def test_refresh_and_exact_bias_variants_against_oracle(name, lanes):
