@@ -17,7 +17,13 @@ _ENV_IDS = {'circle': _lib.ENV_CIRCLE, 'A': _lib.ENV_CIRCLE, 'planar': _lib.ENV_
 
 
 def _ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
+    # a plain int (or None) converts to void* through the argtypes of _lib.py; no c_void_p object per call
+    return t.data_ptr() if t is not None else None
+
+
+# torch.cuda.current_stream(device).cuda_stream builds two Python objects per call (~2 us -- more than the circle
+# kernel runs); the raw accessor PyTorch keeps for extension launchers returns the hipStream_t as an int directly
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
 class BatchedAtacomEnv:
@@ -138,7 +144,9 @@ class BatchedAtacomEnv:
         self._logger = logger
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if _raw_stream is not None:
+            return _raw_stream(self._dev_index)
+        return torch.cuda.current_stream(self.device).cuda_stream
 
     def _as_dev(self, x, shape, dtype=None):
         t = torch.as_tensor(x, dtype=dtype or self.dtype, device=self.device)
