@@ -125,7 +125,8 @@ __device__ __forceinline__ void iiwa_chain9(const T (&q)[9], Chain9<T>& k) {
 }
 
 // tau[9] = M(q) ddq + C(q, dq) dq + g(q); gravity (0, 0, -9.81) enters as an upward acceleration of the base
-template <typename T>
+// ZERO_ACC: all joint accelerations are zero (ddq is not read): tau = C(q, dq) dq + g(q), the bias of the equation of motion
+template <typename T, bool ZERO_ACC = false>
 __device__ __forceinline__ void rnea9(const Chain9<T>& k, const T (&dq)[9], const T (&ddq)[9], T (&tau)[9]) {
     T w[3] = {T(0), T(0), T(0)}, al[3] = {T(0), T(0), T(0)}, ao[3] = {T(0), T(0), T(9.81)};
     T F[9][3], Nm[9][3];
@@ -142,7 +143,7 @@ __device__ __forceinline__ void rnea9(const Chain9<T>& k, const T (&dq)[9], cons
         for (int d = 0; d < 3; ++d) adq[d] = k.a[i][d] * dq[i];
         cross3(w, adq, t1);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { al[d] += num<T>::fma(k.a[i][d], ddq[i], t1[d]); w[d] += adq[d]; }
+        for (int d = 0; d < 3; ++d) { al[d] += ZERO_ACC ? t1[d] : num<T>::fma(k.a[i][d], ddq[i], t1[d]); w[d] += adq[d]; }
         T rc[3], ac[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) rc[d] = k.c[i][d] - k.o[i][d];
@@ -177,10 +178,16 @@ __device__ __forceinline__ void rnea9(const Chain9<T>& k, const T (&dq)[9], cons
     }
 }
 
-// NB x NB leading block of the mass matrix (lower triangle, row-major Ml[i][j], j <= i), composites accumulated from
-// the tip (all nine bodies contribute)
-template <typename T, int NB>
-__device__ __forceinline__ void crba(const Chain9<T>& k, T (&Ml)[NB][NB]) {
+// Mass matrix entries (lower triangle, row-major Ml[i][j], j <= i, j < NB) for the rows i < NR: NR = NB gives the NB x NB
+// leading block of the controlled joints, NR = 9 adds the coupling rows of the three servo joints (M[6..8][0..5], used
+// to put their accelerations on the right-hand side of the controlled joints' equation).  Composites are accumulated
+// from the tip (all nine bodies contribute).
+template <typename T, int NB, int NR = NB>
+__device__ __forceinline__ void crba(const Chain9<T>& k, T (&Ml)[NR][NB]) {
+    static_assert(NR >= NB && NR <= 9, "");
+    T vj[NB][3];                                            // velocity of joint j's body-fixed point at the world origin
+#pragma unroll
+    for (int j = 0; j < NB; ++j) cross3(k.o[j], k.a[j], vj[j]);
     T m = T(0), h[3] = {T(0), T(0), T(0)}, Io[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
 #pragma unroll
     for (int i = 8; i >= 0; --i) {
@@ -195,9 +202,10 @@ __device__ __forceinline__ void crba(const Chain9<T>& k, T (&Ml)[NB][NB]) {
         Io[3] += k.Iw[i][3] + mi * (cc - cy * cy);
         Io[4] += k.Iw[i][4] - mi * cy * cz;
         Io[5] += k.Iw[i][5] + mi * (cc - cz * cz);
-        if (i < NB) {
+        if (i < NR) {
             T vi[3], p[3], L[3], t1[3];
-            cross3(k.o[i], k.a[i], vi);                     // velocity of the body-fixed point at the world origin
+            if (i < NB) { vi[0] = vj[i < NB ? i : 0][0]; vi[1] = vj[i < NB ? i : 0][1]; vi[2] = vj[i < NB ? i : 0][2]; }
+            else cross3(k.o[i], k.a[i], vi);
             cross3(k.a[i], h, t1);
 #pragma unroll
             for (int d = 0; d < 3; ++d) p[d] = num<T>::fma(m, vi[d], t1[d]);
@@ -206,20 +214,20 @@ __device__ __forceinline__ void crba(const Chain9<T>& k, T (&Ml)[NB][NB]) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) L[d] += t1[d];
 #pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                T vj[3];
-                cross3(k.o[j], k.a[j], vj);
+            for (int j = 0; j < NB; ++j) {
+                if (j > i) continue;
                 T v = num<T>::fma(k.a[j][0], L[0], num<T>::fma(k.a[j][1], L[1], k.a[j][2] * L[2]));
-                v = num<T>::fma(vj[0], p[0], num<T>::fma(vj[1], p[1], num<T>::fma(vj[2], p[2], v)));
-                Ml[i < NB ? i : 0][j] = v;
+                v = num<T>::fma(vj[j][0], p[0], num<T>::fma(vj[j][1], p[1], num<T>::fma(vj[j][2], p[2], v)));
+                Ml[i < NR ? i : 0][j] = v;
             }
         }
     }
 }
 
 // x = A^-1 b for the symmetric positive definite A given by its lower triangle (overwritten by its Cholesky factor)
-template <typename T, int NB>
-__device__ __forceinline__ void chol_solve(T (&A)[NB][NB], T (&b)[NB]) {
+// (A may carry NR - NB further rows below the block: they are not touched)
+template <typename T, int NB, int NR = NB>
+__device__ __forceinline__ void chol_solve(T (&A)[NR][NB], T (&b)[NB]) {
     T inv[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {

@@ -250,31 +250,44 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
     for (int i = 0; i < 3; ++i) { q9[6 + i] = st.qx[i]; dq9[6 + i] = st.dqx[i]; }
     Chain9<T> ch;
     iiwa_chain9(q9, ch);
-    T dd[9], tau[9];
+    // The equation of motion is linear in the accelerations, tau = M(q) ddq + h(q, dq), so ONE recursive Newton-Euler
+    // pass (h: all accelerations zero) and the mass-matrix rows the step needs anyway replace the two passes of the literal
+    // formulation (inverse dynamics of the planned acceleration; bias with the servo joints' accelerations):
+    //   tau_c  = clip(M_cc ddq_plan + h_c)                       acc_to_ctrl_action + the URDF effort limits
+    //   M_cc ddq = tau_c - h_c - M_cs ddq_servo - D dq_c          forward dynamics of the six controlled joints
+    T zero9[9], h9[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) dd[i] = (i < 6) ? ddq[i < 6 ? i : 0] : T(0);
-    rnea9(ch, dq9, dd, tau);
+    for (int i = 0; i < 9; ++i) zero9[i] = T(0);
+    rnea9<T, true>(ch, dq9, zero9, h9);
+    T Ml[9][6];                                     // rows 0..5: M_cc (lower triangle); rows 6..8: M_sc = M_cs^T
+    crba<T, 6, 9>(ch, Ml);
     constexpr T effort[6] = {T(320), T(320), T(176), T(176), T(110), T(40)};
+    T tau[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) tau[i] = num<T>::min(num<T>::max(tau[i], -effort[i]), effort[i]);
+    for (int i = 0; i < 6; ++i) {
+        T t = h9[i];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) t = num<T>::fma((j <= i) ? Ml[i][j <= i ? j : 0] : Ml[j][i], ddq[j], t);
+        tau[i] = num<T>::min(num<T>::max(t, -effort[i]), effort[i]);
+    }
     const T q6[6] = {st.q[0], st.q[1], st.q[2], st.q[3], st.q[4], st.q[5]};
     const T tgt[3] = {joint7_target(q6, st.qx[0]), universal_target(ch.a[6], ch.a[7]), T(0)};
     constexpr T vmax[3] = {T(1.5 * 2.356194490192345), T(1.5 * 3.1415926), T(1.5 * 3.1415926)};     // urdf:297,384,397
-    T vstar[3];
+    T vstar[3], dds[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         vstar[i] = num<T>::min(num<T>::max(T(0.1) * (tgt[i] - st.qx[i]) / P.dt, -vmax[i]), vmax[i]);
-        dd[6 + i] = (vstar[i] - st.dqx[i]) / P.dt;
+        dds[i] = (vstar[i] - st.dqx[i]) / P.dt;
     }
+    T rhs[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) dd[i] = T(0);
-    T bias[9];
-    rnea9(ch, dq9, dd, bias);
-    T rhs[6], Ml[6][6];
+    for (int i = 0; i < 6; ++i) {
+        T r = tau[i] - h9[i] - (T)iiwa_body::DAMPING[i] * st.dq[i];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) rhs[i] = tau[i] - bias[i] - (T)iiwa_body::DAMPING[i] * st.dq[i];
-    crba<T, 6>(ch, Ml);
-    chol_solve<T, 6>(Ml, rhs);
+        for (int s2 = 0; s2 < 3; ++s2) r = num<T>::fma(-Ml[6 + s2][i], dds[s2], r);
+        rhs[i] = r;
+    }
+    chol_solve<T, 6, 9>(Ml, rhs);
 #pragma unroll
     for (int i = 0; i < 6; ++i) ddq[i] = rhs[i];
 #pragma unroll

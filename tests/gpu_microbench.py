@@ -40,7 +40,7 @@ for name in sys.argv[1:] or ['iiwa']:
             e1.record(); torch.cuda.synchronize()
             ur = e0.elapsed_time(e1) / (5 * T) * 1e3
             msg = 'rollout %.1f us/step' % ur
-            if name != 'circle':
+            if name != 'circle' and not os.environ.get('MB_DYN'):      # (no rigid-body form of the policy kernels)
                 g2 = torch.Generator(device='cpu'); g2.manual_seed(0)
                 D = env.obs_dim
                 W = [torch.randn((64, D), generator=g2) * 0.1, torch.zeros(64), torch.randn((64, 64), generator=g2) * 0.1,
