@@ -61,7 +61,7 @@ def test_shard_bounds_cover_the_batch():
         assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])       # 8: the shard count of BASELINE config 5 (ragged: 10 envs over 8 ranks)
 def test_two_rank_gloo_rollout_equals_single_process(world):
     from oracle_engine import OracleEngine
     ctx = mp.get_context('spawn')
