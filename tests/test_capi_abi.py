@@ -46,6 +46,16 @@ def test_config_layout_and_reference_constants(lib_built):
         assert np.allclose(list(cfg.base_xy), spec.base_xy)
 
 
+def test_integration_doc_binding_stub_matches_the_struct():
+    """INTEGRATION.md section 2 shows a maintainer the ctypes mirror of atacom_config: its field list must be the one
+    of the shipped binding (it drifted once when dt_base was added)."""
+    from rl_on_manifold_amd import _lib
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    body = doc[doc.index('class AtacomConfig(C.Structure)'):]
+    body = body[:body.index(']\n\ncfg = AtacomConfig()')]
+    assert re.findall(r'\("(\w+)", C\.', body) == [f[0] for f in _lib.AtacomConfig._fields_]
+
+
 def test_error_reporting_without_gpu(lib_built):
     from rl_on_manifold_amd import _lib
     lib = _lib.load()
