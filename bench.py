@@ -356,6 +356,8 @@ def main():
                   'two_collections_overlapped_ms': t_pipe * 1e3 if t_pipe else None,
                   'backend': backend if world > 1 else None}
     del gathered
+    if world == 1 and backend == 'nccl':
+        collection['rccl_world1_selfgather'] = rccl_selfgather(env, rec, dev)
 
     # ---- the same collection with the actor MLP (18-64-64-5, random weights) + Gaussian noise inside the kernel (row N2)
     pol_rate = None
@@ -416,6 +418,44 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+def rccl_selfgather(env, rec, dev, reps=5):
+    """N = 1 only: the packed record buffer of the collection above through the real RCCL all_gather_into_tensor -- a
+    process group of ONE rank, the collector told not to short-circuit.  No xGMI hop, so this is a LOWER bound on what
+    the collective adds to a collection (launch, buffer registration, the device-side copy); the N > 1 lines carry the
+    measured all-gather.  Never fatal: a box whose RCCL cannot initialise reports the error string instead."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from rl_on_manifold_amd.rollout import RolloutCollector
+    if dist.is_initialized():
+        return None
+    try:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        try:
+            col = RolloutCollector(env, force_collective=True)
+            g = col.gather(rec)
+            torch.cuda.synchronize(dev)
+            same = bool(torch.equal(g[0], rec))
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                col.gather(rec)
+                torch.cuda.synchronize(dev)
+                ts.append(time.perf_counter() - t0)
+            nbytes = rec.numel() * rec.element_size()
+            ms = float(np.median(ts)) * 1e3
+            return {'ms': ms, 'bytes': nbytes, 'GBps': nbytes / ms / 1e6, 'identical': same, 'backend': 'nccl (RCCL)',
+                    'note': 'world of one rank, force_collective: lower bound on the collective (no xGMI hop)'}
+        finally:
+            dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        return {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
 
 
 def secondary_records(dev, gen, K, W, sync_all, max_over_ranks):

@@ -18,7 +18,7 @@ def __getattr__(name):
                 'CircleEnvTerminated', 'VectorizedAtacomEnv'):
         from . import envs
         return getattr(envs, name)
-    if name == 'RolloutCollector':
+    if name in ('RolloutCollector', 'RecordLayout'):
         from . import rollout
-        return rollout.RolloutCollector
+        return getattr(rollout, name)
     raise AttributeError(name)

@@ -13,7 +13,9 @@ Data path of one collection (every pass over the data is listed; there are two):
      ("shard-major"): `unpack` returns views into it, `reshape(-1, F)` is the flat sample set a PPO / TRPO fit
      consumes, and the time axis of every environment stays strided-contiguous for GAE.
 No size exchange (every rank's shard size is a pure function of (global_batch, world)), no packing copy, no
-concatenation.  For config 5: 120 x 8192 x 44 floats = 173 MB sent per rank, 1.38 GB received; xGMI is
+concatenation.  Ragged shards (global_batch not a multiple of the world size) are padded to the largest shard: block r
+of the gathered buffer holds sizes[r] valid env rows followed by ZERO rows, so `reshape(-1, F)` of a ragged gather also
+contains those padding records -- `RecordLayout.valid_mask()` selects the real ones, `time_major()` drops them.  For config 5: 120 x 8192 x 44 floats = 173 MB sent per rank, 1.38 GB received; xGMI is
 point-to-point, so one large collective amortises the per-link setup far better than six small ones.
 Constraint statistics are reduced with one MAX and one SUM all-reduce of two numbers each.
 """
@@ -28,6 +30,36 @@ def shard_bounds(global_batch, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class RecordLayout:
+    """The shard-major layout of a gathered collection, [W, T, Bm, F] with F = 2 D + k + 3 packed floats per (step, env):
+    [obs | action | reward | next_obs | absorbing | last].  Pure index arithmetic -- usable without a process group
+    (e.g. for a buffer that several engines of ONE process filled block by block)."""
+
+    def __init__(self, sizes, obs_dim, n_null):
+        self.sizes = [int(s) for s in sizes]
+        self.world = len(self.sizes)
+        self.Bm = max(self.sizes)
+        self.D, self.k = int(obs_dim), int(n_null)
+        self.F = 2 * self.D + self.k + 3
+
+    def unpack(self, g):
+        """Views (no copy) into records [..., F]."""
+        D, k = self.D, self.k
+        return {'obs': g[..., :D], 'action': g[..., D:D + k], 'reward': g[..., D + k],
+                'next_obs': g[..., D + k + 1:2 * D + k + 1], 'absorbing': g[..., 2 * D + k + 1] > 0.5,
+                'last': g[..., 2 * D + k + 2] > 0.5}
+
+    def time_major(self, data):
+        """[W, T, Bm, ...] -> [T, B_global, ...] with rank r's envs in block shard_bounds(global_batch, W, r); the
+        padding rows of ragged shards are dropped.  This one COPIES (a permute + concatenation)."""
+        return {key: torch.cat([v[r, :, :self.sizes[r]] for r in range(self.world)], 1) for key, v in data.items()}
+
+    def valid_mask(self, device=None):
+        """bool [W, Bm]: True where block r, env row b is a real environment (False on the padding of ragged shards)."""
+        idx = torch.arange(self.Bm, device=device)
+        return idx[None, :] < torch.tensor(self.sizes, device=device)[:, None]
+
+
 class RolloutCollector:
     """Drive one local engine (a BatchedAtacomEnv, or anything with its surface) and assemble global rollouts.
 
@@ -37,9 +69,13 @@ class RolloutCollector:
                    shards follow shard_bounds(global_batch, world, rank) and are padded to the largest shard
     """
 
-    def __init__(self, env, group=None, global_batch=None):
+    def __init__(self, env, group=None, global_batch=None, force_collective=False):
         self.env = env
         self.group = group
+        # force_collective: run the collectives even in a world of one rank (they are a copy through the backend then):
+        # the way to exercise the RCCL transport -- buffer registration, the backend's stream, async work objects -- on a
+        # single GPU.  Needs an initialised process group.
+        self.force_collective = bool(force_collective)
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.rank = dist.get_rank(group) if self.distributed else 0
@@ -55,6 +91,7 @@ class RolloutCollector:
         self.k = env.dims['null']
         self.D = env.obs_dim
         self.F = 2 * self.D + self.k + 3          # obs, action, reward, next_obs, absorbing, last
+        self.layout = RecordLayout(self.sizes, self.D, self.k)
         self._recv = None
 
     # ------------------------------------------------------------------ local collection
@@ -96,6 +133,8 @@ class RolloutCollector:
             nobs, ab, last = torch.stack(nobs_l), torch.stack(ab_l), torch.stack(last_l)
         T = obs.shape[0]
         buf = torch.zeros((T, self.Bm, self.F), device=obs.device, dtype=obs.dtype) if out is None else out
+        if out is not None and self.Bm > B:
+            out[:, B:] = 0                         # a caller's buffer may hold anything: the padding rows are zero
         D, k = self.D, self.k
         buf[:, :B, :D] = obs
         buf[:, :B, D:D + k] = act
@@ -113,16 +152,22 @@ class RolloutCollector:
         on-policy learner consumes a dataset before collecting the next one); pass `out` or clone to keep it.
         async_op=True returns (result, work): the collective runs on the backend's own stream (RCCL) while the caller
         goes on -- e.g. launches the next rollout -- and `work.wait()` orders the result before its first use."""
-        if self.world == 1:
+        if self.world == 1 and not (self.force_collective and self.distributed):
+            if out is not None:
+                out.view(buf.shape).copy_(buf)
+                return (out, _Done()) if async_op else out
             return (buf.unsqueeze(0), _Done()) if async_op else buf.unsqueeze(0)
         T, Bm, F = buf.shape
         shape = (self.world, T, Bm, F)
+        if out is not None and (tuple(out.shape) != shape or out.dtype != buf.dtype or not out.is_contiguous()):
+            raise ValueError("out must be a contiguous %s tensor of dtype %s" % (shape, buf.dtype))
         if buf.is_cuda and dist.get_backend(self.group) == 'gloo':
             # gloo moves host memory: the control-flow check mode (several ranks sharing one GPU in the tests;
             # BENCH_DIST_BACKEND=gloo).  The production transport is RCCL, device to device, below.
             host = torch.empty(shape, dtype=buf.dtype)
             dist.all_gather_into_tensor(host.view(self.world * T, Bm, F), buf.cpu(), group=self.group)
-            return (host.to(buf.device), _Done()) if async_op else host.to(buf.device)
+            res = host.to(buf.device) if out is None else out.copy_(host)
+            return (res, _Done()) if async_op else res
         if out is None:
             if self._recv is None or tuple(self._recv.shape) != shape or self._recv.dtype != buf.dtype \
                     or self._recv.device != buf.device:
@@ -134,19 +179,13 @@ class RolloutCollector:
 
     def unpack(self, g):
         """Views (no copy) into gathered records [W, T, Bm, F]: every entry is [W, T, Bm, ...]."""
-        D, k = self.D, self.k
-        return {'obs': g[..., :D], 'action': g[..., D:D + k], 'reward': g[..., D + k],
-                'next_obs': g[..., D + k + 1:2 * D + k + 1], 'absorbing': g[..., 2 * D + k + 1] > 0.5,
-                'last': g[..., 2 * D + k + 2] > 0.5}
+        return self.layout.unpack(g)
 
     def time_major(self, data):
         """[W, T, Bm, ...] -> [T, B_global, ...] with rank r's envs in block shard_bounds(global_batch, W, r).
         This one COPIES (a permute + concatenation); it is for consumers that insist on a single env axis and for
         comparing against a single-process run -- the collection path itself never needs it."""
-        out = {}
-        for key, v in data.items():
-            out[key] = torch.cat([v[r, :, :self.sizes[r]] for r in range(self.world)], 1)
-        return out
+        return self.layout.time_major(data)
 
     def collect(self, n_steps, actions=None, policy=None, noise=None):
         """Local rollout + global all-gather.  Returns the unpacked global dataset, shard-major [W, T, Bm, ...]."""
@@ -166,7 +205,7 @@ class RolloutCollector:
         """Global (c_avg, c_max, c_dq_max): the reference's get_constraints_logs (atacom.py:207-216) over every env
         of every rank.  n_logged = number of (env, step) entries this rank logged since the last call."""
         c_avg, c_max, c_dq = self.env.get_constraints_logs()
-        if self.world == 1:
+        if self.world == 1 and not (self.force_collective and self.distributed):
             return c_avg, c_max, c_dq
         dev = getattr(self.env, 'device', torch.device('cpu'))
         if self.distributed and dist.get_backend(self.group) == 'gloo':

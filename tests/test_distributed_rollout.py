@@ -90,6 +90,58 @@ def test_two_rank_gloo_rollout_equals_single_process(world):
     assert np.allclose(d0['obs'][5], d0['obs'][0])          # auto-reset: step 5 starts from the initial state
 
 
+def _solo_worker(port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        from oracle_engine import OracleEngine
+        eng = OracleEngine(NAME, 4, init_q=_init_q()[:4], horizon=5)
+        col = RolloutCollector(eng, force_collective=True)
+        local = col.collect_local(T, actions=_actions()[:, :4])
+        out = torch.full((1,) + tuple(local.shape), float('nan'), dtype=local.dtype)
+        g = col.gather(local, out=out)                            # the collective runs although world == 1 ...
+        ok = g.data_ptr() == out.data_ptr() and torch.equal(out[0], local)       # ... and fills the caller's buffer
+        g2, work = col.gather(local, async_op=True)
+        work.wait()
+        ok = ok and torch.equal(g2[0], local) and g2.data_ptr() != local.data_ptr()
+        stats = col.get_constraints_logs(n_logged=T * 4)          # all-reduces of one rank
+        q.put((ok, stats))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_collective_in_a_world_of_one_rank():
+    """force_collective=True sends a one-rank world through the real all-gather / all-reduce calls (the CPU twin of the
+    RCCL world-1 test in test_gpu_rollout.py)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_solo_worker, args=(31500 + (os.getpid() % 2000), q))
+    p.start()
+    ok, stats = q.get(timeout=180)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and ok and np.isfinite(stats).all()
+
+
+def test_record_layout_ragged_padding():
+    from rl_on_manifold_amd.rollout import RecordLayout
+    lay = RecordLayout([3, 2, 2], obs_dim=4, n_null=1)
+    assert lay.F == 12 and lay.Bm == 3
+    g = torch.arange(3 * 5 * 3 * 12, dtype=torch.float32).reshape(3, 5, 3, 12)
+    m = lay.valid_mask()
+    assert m.tolist() == [[True, True, True], [True, True, False], [True, True, False]]
+    tm = lay.time_major(lay.unpack(g))
+    assert tm['obs'].shape == (5, 7, 4) and torch.equal(tm['reward'][:, 3], g[1, :, 0, 5])
+    # a caller-supplied send buffer gets its padding rows zeroed by the fallback packing path
+    from oracle_engine import OracleEngine
+    eng = OracleEngine('circle', 2, horizon=6)
+    col = RolloutCollector(eng)
+    col.Bm = 3                                                   # as on the short rank of a ragged split
+    out = torch.full((4, 3, col.F), 7.0, dtype=torch.float64)
+    buf = col.collect_local(4, actions=np.zeros((4, 2, 1)), out=out)
+    assert (buf[:, 2] == 0).all() and torch.isfinite(buf).all()
+
+
 def test_policy_driven_collection_and_mushroom_dataset():
     from oracle_engine import OracleEngine
     eng = OracleEngine('circle', 4, horizon=6)

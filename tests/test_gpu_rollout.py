@@ -156,6 +156,139 @@ def test_collector_two_processes_sharing_the_gpu_equal_one_process():
         assert np.allclose(stats, ref_stats, rtol=1e-6, atol=1e-7)
 
 
+# ---------------------------------------------------------------------------------------------- BASELINE config 5
+def _config5_shard(r, B, T):
+    """Shard r of config 5 exactly as bench.py builds a rank's workload: feasible initial states,
+    auto-reset at the horizon, uniform actions."""
+    sys.path.insert(0, ROOT)
+    import bench
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(1234 + r)
+    env, init, _ = bench.make_env('iiwa', B, torch.device(DEV), gen)
+    acts = torch.rand((T, B, 5), device=DEV, generator=gen) * 2 - 1
+    return env, init, acts
+
+
+def test_config5_dress_rehearsal_eight_shards_on_one_gpu():
+    """BASELINE config 5 at full size, everything but the xGMI hop: 8 engines x 8192 IiwaAirHockey environments on ONE
+    device, each rolled out for the full 120-step horizon by one launch straight into ITS block of the final
+    [8, 120, 8192, 44] buffer (1.38 GB) -- the layout the all-gather produces on every rank."""
+    from rl_on_manifold_amd import RecordLayout
+    W, B, T = 8, 8192, 120
+    shards = [_config5_shard(r, B, T) for r in range(W)]
+    env0 = shards[0][0]
+    F = env0.record_dim
+    assert F == 44
+    buf = torch.empty((W, T, B, F), device=DEV)
+    for r, (env, _, acts) in enumerate(shards):
+        env.get_constraints_logs()
+        env.rollout_packed(actions=acts, out=buf[r])
+    torch.cuda.synchronize()
+    stats = np.array([env.get_constraints_logs() for env, _, _ in shards])
+    assert bool(torch.isfinite(buf).all())
+    lay = RecordLayout([B] * W, env0.obs_dim, 5)
+    data = lay.unpack(buf)
+    # episodes end at the horizon -- step 120 of an environment that never hit an absorbing state -- or earlier by
+    # absorbing (then the auto-reset restarts its step counter); absorbing implies last
+    quiet = ~data['absorbing'].any(1)                          # [W, B]
+    assert float(quiet.float().mean()) > 0.5
+    assert data['last'][:, -1][quiet].all() and not data['last'][:, :-1].permute(0, 2, 1)[quiet].any()
+    assert not (data['absorbing'] & ~data['last']).any()
+    # the constraint metric of the whole 7.9 M env-steps, from feasible initial states
+    assert stats[:, 1].max() < 0.05, stats
+    assert stats[:, 2].max() <= 1e-4, stats
+    # (i) the shard-major buffer, time-majored, IS the single-engine array rollout of every shard
+    tm = lay.time_major(data)
+    assert tm['obs'].shape == (T, W * B, env0.obs_dim)
+    for r in (0, 3, 7):
+        env, init, acts = shards[r]
+        env.reset(state=init)
+        ref = env.rollout(acts)
+        for key in KEYS:
+            assert torch.equal(tm[key][:, r * B:(r + 1) * B].float(), ref[key].float()), (r, key)
+    # (ii) ONE 65536-environment engine (one environment per lane instead of per lane group) on the concatenated states
+    # and actions: same episodes.  The two mappings round differently and the closed loop amplifies that (DESIGN.md
+    # section 2), so: first step to float32 tolerance, the later ones in distribution.
+    from rl_on_manifold_amd import BatchedAtacomEnv
+    big = BatchedAtacomEnv('iiwa', W * B, device=DEV, dtype=torch.float32, auto_reset=True)
+    assert big.rollout_lanes_per_env == 1 and env0.rollout_lanes_per_env == 8
+    big.reset(state=torch.cat([s[1] for s in shards]))
+    sub = slice(0, None, 61)                                    # a subsample of the 65536 environments
+    ref = big.rollout(torch.cat([s[2] for s in shards], 1))
+    big_stats = big.get_constraints_logs()
+    d0 = (ref['next_obs'][0] - tm['next_obs'][0]).abs().max(1).values
+    assert float((d0 < 2e-4).float().mean()) > 0.995 and float(d0.median()) < 2e-6
+    dm = (ref['next_obs'][:, sub] - tm['next_obs'][:, sub]).abs().amax(2)
+    assert float(dm[:10].median()) < 1e-5
+    assert torch.equal(ref['last'][-1].bool(), tm['last'][-1])
+    assert 0.5 < big_stats[1] / stats[:, 1].max() < 2.0 and big_stats[2] <= 1e-4
+    big.close()
+    for env, _, _ in shards:
+        env.close()
+
+
+def _rccl_world1_worker(port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch.distributed as dist
+    dev = torch.device(DEV)
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        from rl_on_manifold_amd.rollout import RolloutCollector
+        B, T = 8192, 120
+        env, _, acts = _config5_shard(0, B, T)
+        col = RolloutCollector(env, force_collective=True)
+        assert dist.get_backend() == 'nccl'
+        rec = col.collect_local(T, actions=acts)
+        assert rec.is_cuda and rec.numel() * 4 == 173015040          # the real 173 MB record buffer of one rank
+        g = col.gather(rec)                                           # blocking all_gather_into_tensor on device tensors
+        torch.cuda.synchronize()
+        ok = [g.is_cuda and tuple(g.shape) == (1, T, B, 44) and g.data_ptr() != rec.data_ptr() and torch.equal(g[0], rec)]
+        out = torch.full((1, T, B, 44), float('nan'), device=dev)
+        g2, work = col.gather(rec, out=out, async_op=True)            # async_op on RCCL's stream + work.wait()
+        work.wait()
+        ok.append(g2.data_ptr() == out.data_ptr() and torch.equal(out[0], rec))
+        # collect_async: rollout kernel -> all-gather in flight -> a second rollout on the compute stream meanwhile
+        env2, _, acts2 = _config5_shard(0, B, T)
+        col2 = RolloutCollector(env2, force_collective=True)
+        out2 = torch.empty((1, T, B, 44), device=dev)
+        pend = col2.collect_async(T, actions=acts2, out=out2)
+        rec_b = env.rollout_packed(actions=acts)                      # overlaps the collective
+        data = pend.wait()
+        torch.cuda.synchronize()
+        ok.append(torch.equal(out2[0], rec))                          # same seed, same states: the same records
+        ok.append(bool(torch.isfinite(rec_b).all()) and data['obs'].shape == (1, T, B, 18))
+        stats = col.get_constraints_logs(n_logged=2 * T * B)          # MAX / SUM all-reduces over RCCL
+        ok.append(bool(np.isfinite(stats).all()))
+        # timing of the self-gather: a lower bound on what the collective costs per collection
+        import time
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            col.gather(rec)
+        torch.cuda.synchronize()
+        q.put((ok, (time.perf_counter() - t0) / 5 * 1e3))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_all_gather_path_executes_world_1():
+    """The production transport at last: `nccl` (= RCCL) process group of ONE rank, and the collector told not to
+    short-circuit -- the 173 MB packed record buffer of a config-5 rank goes through all_gather_into_tensor on device
+    memory (blocking, async_op + wait, collect_async) and the statistics through RCCL all-reduces."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(30800 + (os.getpid() % 1000), q))
+    p.start()
+    ok, ms = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert all(ok), ok
+    print('RCCL world-1 self-gather of 173 MB: %.3f ms' % ms)
+
+
 def test_calls_leave_the_current_device_alone():
     """no entry point may change the calling thread's current HIP device."""
     if torch.cuda.device_count() < 2:
