@@ -143,9 +143,11 @@ def bidiag_solve_null(Jc, rhs, k, cond=None):
     return X[:, :, 0], X[:, :, 1:]
 
 
-def rref_tol(N, tol, margin=None):
+def rref_tol(N, tol, margin=None, skipped=None):
     """Batched null_space_coordinate.rref(N, row_vectors=False, tol) (lines 40-79).
     margin (optional, [B], updated in place with minimum): how far the DISCRETE decisions of the elimination were from
+    `skipped` (optional bool [B], OR-updated): the elimination took the tolerance branch (:56-63) at least once, i.e. the
+    result is NOT the reduced echelon basis with the first k coordinates free (and has been zeroed somewhere).
     going the other way -- |p - tol| of every pivot-or-skip test (:56-63) and the gap between the largest and the
     second largest candidate of every arg-max (:55).  A float32 evaluation of the same matrix can only take a different
     branch where this margin is of the order of its rounding error; the parity tests use it to separate "arithmetic
@@ -172,6 +174,8 @@ def rref_tol(N, tol, margin=None):
             margin[:] = np.where(active, np.minimum(margin, mg), margin)
         piv = active & (p > tol)
         skip = active & ~piv
+        if skipped is not None:
+            skipped |= skip
         # negligible column: zero it from row i down
         zero_mask = skip[:, None] & (rows >= i[:, None])
         V[:, :, j] = np.where(zero_mask, 0.0, V[:, :, j])
@@ -297,11 +301,26 @@ class BatchedAtacomEnv:
         psi = Jdq + sp.K * bst
         c = fun + sp.K * Jdq
         c[:, nf:] += 0.5 * s ** 2
+        if sp.mode == MODE_ATACOM and getattr(sp, 'chart_mode', 0) == 1:
+            # opt-in canonical chart: same mu wherever the reference's rref takes no tolerance branch, an exact null basis
+            # everywhere (oracle/canonical_chart.py)
+            from .canonical_chart import canonical_mu
+            A = Jc[:, :, :nq]
+            if noise is not None:
+                A = (sp.K[None, :, None] * J + 0.0) * (1.0 + noise[0] * noise[1].choice([-1.0, 1.0], A.shape))
+            info = getattr(self, 'chart_info', None)
+            track = getattr(self, 'chart_default', None)
+            if track is not None and info is None:
+                info = {}
+            mu = canonical_mu(A, s, psi + sp.Kc * c, alpha, sp.rref_tol, nf, getattr(self, 'decision_margin', None), info)
+            if track is not None:
+                track &= info['default']          # the default chart (first k joints free) in EVERY sub-step of the step
+            return mu
         if sp.mode == MODE_ERROR_CORRECTION:       # error_correction_wrapper.py:117-130
             x, _ = bidiag_solve_null(Jc, sp.Kc * c, sp.n_null)
             return np.concatenate([alpha, np.zeros((B, ng))], -1) - x
         x, N = bidiag_solve_null(Jc, psi + sp.Kc * c, sp.n_null, getattr(self, 'cond_number', None))
-        Nr = rref_tol(N, sp.rref_tol, getattr(self, 'decision_margin', None))
+        Nr = rref_tol(N, sp.rref_tol, getattr(self, 'decision_margin', None), getattr(self, 'chart_skipped', None))
         return -x + np.einsum('bnk,bk->bn', Nr, alpha)
 
     def acc_truncation(self, dq, ddq):
@@ -317,11 +336,13 @@ class BatchedAtacomEnv:
         contact_margin [B]  -- the puck model's tests (contact distance, approach speed, rims, goal mouth, hit latch,
                                absorbing thresholds), in metres / metres per second."""
         if on:
+            self.chart_skipped = np.zeros(self.B, dtype=bool)   # the reference's rref took its tolerance branch this step
+            self.chart_default = np.ones(self.B, dtype=bool)    # canonical chart: the default chart in every sub-step
             self.decision_margin = np.full(self.B, np.inf)
             self.contact_margin = np.full(self.B, np.inf)
             self.cond_number = np.zeros(self.B)          # largest sigma_max / sigma_min of J_c over the sub-steps
         else:
-            for k in ('decision_margin', 'contact_margin', 'cond_number'):
+            for k in ('decision_margin', 'contact_margin', 'cond_number', 'chart_skipped', 'chart_default'):
                 self.__dict__.pop(k, None)
 
     def _cm(self, values, where=None):
@@ -334,6 +355,8 @@ class BatchedAtacomEnv:
         sp = self.spec
         nq = sp.dim_q
         if hasattr(self, 'decision_margin'):
+            self.chart_skipped[:] = False
+            self.chart_default[:] = True
             self.decision_margin[:] = np.inf
             self.contact_margin[:] = np.inf
             self.cond_number[:] = 0.0
@@ -372,7 +395,7 @@ class BatchedAtacomEnv:
                 mu = self.tangent_space_accel(q_ctl, dq_ctl, self.s, alpha, terms)
                 self.s = self.s + mu[:, nq:] * sp.dt
                 ddq = self.acc_truncation(dq_ctl, mu[:, :nq])
-                if sp.dynamics_mode == 1:
+                if sp.dynamics_mode >= 1:
                     ddq = self._rigid_body_substep(q_sim, dq_sim, ddq)
                 dq_sim = np.clip(dq_sim + ddq * sp.dt, -1.5 * sp.vel_max, 1.5 * sp.vel_max)
                 q_sim = q_sim + dq_sim * sp.dt
@@ -391,30 +414,40 @@ class BatchedAtacomEnv:
         return self.observation(), reward, absorbing, {}
 
     SERVO_GAIN = 0.1          # PyBullet's default positionGain of POSITION_CONTROL (env_base.py:64-70)
+    SERVO_EFFORT = np.array([40.0, 10.0, 10.0])      # urdf/iiwa_1.urdf:297,384,400: joint_7, striker_joint_1 / _2
 
     def _rigid_body_substep(self, q_sim, dq_sim, ddq_des):
-        """Row N4, dynamics_mode = 1 (the model of this build where Bullet was), per sub-step:
+        """Row N4, dynamics_mode >= 1 (the model of this build where Bullet was), per sub-step:
           tau  = inverse dynamics of the nine-joint chain for [ddq_des, 0, 0, 0]   (acc_to_ctrl_action,
-                 iiwa_hit_atacom.py:58-63)
+                 iiwa_hit_atacom.py:58-63); dynamics_mode 2: for [ddq_des, ddq_b] -- the controller knows what the servo
+                 joints are about to do (feed-forward of their reaction; NOT what the reference computes)
           servo joints (joint 7, universal joint; POSITION_CONTROL, env_base.py:64-70): velocity set-point
-                 v* = clip(gain (target - q) / dt, 1.5 v_max), targets from env_single.py:137-185; ddq_b = (v* - dq_b) / dt
+                 v* = clip(gain (target - q) / dt, 1.5 v_max), targets from env_single.py:137-185; the motor realises
+                 ddq_b = (v* - dq_b) / dt as far as its torque allows: |M_bb,ii ddq_b,i + h_b,i| <= URDF effort limit
+                 (diagonal estimate of the motor torque; h = gravity + Coriolis at the simulated state)
           ddq_a = forward dynamics of the six controlled joints under tau, URDF joint damping and the servo joints'
-                 prescribed accelerations.
+                 accelerations.
         Advances the servo joints; returns ddq_a (the caller integrates the controlled joints)."""
         from . import dynamics as D
         sp = self.spec
         B = q_sim.shape[0]
         q9 = np.concatenate([q_sim, self.qx], 1)
         dq9 = np.concatenate([dq_sim, self.dqx], 1)
-        tau = D.rnea(q9, dq9, np.concatenate([ddq_des, np.zeros((B, 3))], 1))[:, :6]
         tgt = np.concatenate([D.joint7_target(q_sim, self.qx[:, 0])[:, None],
                               D.universal_joint_target(q9[:, :7])], 1)
         vmax = 1.5 * np.array([robots.IIWA_VEL_LIMIT[6], 3.1415926, 3.1415926])     # iiwa_1.urdf:297,384,397
         vstar = np.clip(self.SERVO_GAIN * (tgt - self.qx) / sp.dt, -vmax, vmax)
         ddq_b = (vstar - self.dqx) / sp.dt
+        h = D.rnea(q9, dq9, np.zeros((B, 9)))
+        Mbb = np.einsum('bii->bi', D.mass_matrix(q9))[:, 6:]
+        lim = np.maximum(self.SERVO_EFFORT - np.abs(h[:, 6:]), 0.0) / Mbb
+        ddq_b = np.clip(ddq_b, -lim, lim)
+        ff = ddq_b if sp.dynamics_mode == 2 else np.zeros((B, 3))
+        tau = D.rnea(q9, dq9, np.concatenate([ddq_des, ff], 1))[:, :6]
+        tau = np.clip(tau, -D.EFFORT_LIMIT, D.EFFORT_LIMIT)
         ddq_a = D.forward_dynamics(q9, dq9, tau, ddq_b)
-        self.dqx = vstar
-        self.qx = self.qx + vstar * sp.dt
+        self.dqx = self.dqx + ddq_b * sp.dt
+        self.qx = self.qx + self.dqx * sp.dt
         return ddq_a
 
     def _puck_substep(self, mallet, mallet_vel):

@@ -58,6 +58,8 @@ class EnvSpec:
     base_dt: float = 0.0     # time step of the BASE env when it differs from the wrapper's (quirk Q4: CircleEnvAtacom /
                              # CircleEnvErrorCorrection hand time_step to the wrapper only, circle_atacom.py:7-18 -- the
                              # base CircularMotion keeps its default 0.01); 0 = same as dt
+    chart_mode: int = 0      # 0: the reference's chart (LAPACK null basis + rref with tolerance); 1: the canonical chart
+                             # (oracle/canonical_chart.py; opt-in) -- batched oracle only
     dynamics_mode: int = 0   # 0: inverse o forward dynamics = identity; 1: rigid body (row N4, iiwa,
                              # oracle/dynamics.py -- implemented by the batched oracle only)
 

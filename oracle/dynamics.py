@@ -24,6 +24,10 @@ from . import iiwa_inertial as II
 N_BODY = 9
 
 
+# URDF effort limits of the six controlled joints (urdf/iiwa_1.urdf:74,112,149,186,223,260)
+EFFORT_LIMIT = np.array([320.0, 320.0, 176.0, 176.0, 110.0, 40.0])
+
+
 def _rot(axis, q):
     """Rotation by q about a coordinate axis ('x' / 'y' / 'z'), batched: [B, 3, 3]."""
     c, s = np.cos(q), np.sin(q)

@@ -17,7 +17,7 @@ MAX_C, MAX_Q = 12, 6
 EXPORTS = ['atacom_rollout_mlp', 'atacom_rollout_packed', 'atacom_get_aux_state', 'atacom_set_aux_state',
            'atacom_inverse_dynamics', 'atacom_forward_dynamics', 'atacom_default_config', 'atacom_get_dims', 'atacom_create', 'atacom_destroy', 'atacom_reset',
            'atacom_step', 'atacom_rollout', 'atacom_get_stats', 'atacom_get_state', 'atacom_set_state',
-           'atacom_nullspace', 'atacom_constraint_terms', 'atacom_last_error', 'atacom_version', 'atacom_get_lanes']
+           'atacom_nullspace', 'atacom_constraint_terms', 'atacom_step_masked', 'atacom_canonical_mu', 'atacom_last_error', 'atacom_version', 'atacom_get_lanes']
 
 
 class AtacomConfig(C.Structure):
@@ -29,7 +29,7 @@ class AtacomConfig(C.Structure):
                 ('K', C.c_double * MAX_C), ('Kc', C.c_double * MAX_C), ('vel_max', C.c_double * MAX_Q),
                 ('acc_max', C.c_double * MAX_Q), ('Kq', C.c_double * MAX_Q), ('pos_limit', C.c_double * MAX_Q),
                 ('base_xy', C.c_double * 2), ('link', C.c_double * 3), ('term_tol', C.c_double), ('random_init', C.c_int32), ('seed', C.c_int32),
-                ('dynamics_mode', C.c_int32), ('reserved0', C.c_int32), ('dt_base', C.c_double)]
+                ('dynamics_mode', C.c_int32), ('chart_mode', C.c_int32), ('dt_base', C.c_double)]
 
 
 class AtacomMlp(C.Structure):
@@ -80,6 +80,8 @@ def load():
     lib.atacom_destroy.argtypes = [vp]
     lib.atacom_reset.argtypes = [vp, u8p, vp, vp, vp]
     lib.atacom_step.argtypes = [vp, vp, vp, vp, u8p, u8p, vp]
+    lib.atacom_step_masked.argtypes = [vp, u8p, vp, vp, vp, u8p, u8p, vp]
+    lib.atacom_canonical_mu.argtypes = [i32, i32, i32, vp, vp, vp, vp, C.c_double, vp, vp]
     lib.atacom_rollout.argtypes = [vp, i32, vp, vp, vp, vp, u8p, u8p, vp]
     lib.atacom_rollout_mlp.argtypes = [vp, i32, C.POINTER(AtacomMlp), vp, vp, vp, vp, vp, u8p, u8p, vp]
     lib.atacom_rollout_packed.argtypes = [vp, i32, vp, C.POINTER(AtacomMlp), vp, vp, i32, vp]

@@ -71,11 +71,16 @@ constexpr int kStatBlocks = 256;
 // state in registers, no per-step launch phase -- keep the 8-lane advantage (22.8 vs 23.9 us per step, with the policy
 // network 25.0 vs 26.5) and take it.  The state layout does not depend on the mapping, so the kernels of one handle may
 // differ.  planar (6 x 9): the quad is the widest that pays.
+// Two variants run fewer mappings: the rigid-body kernels (dynamics_mode 1) exist per lane and per quad only -- 8 -> 4,
+// 2 -> 1, and atacom_get_lanes reports what really runs; the canonical chart (chart_mode 1) does its small solve per
+// lane, so the automatic choice is one environment per lane (a wider group only repeats the work; explicit requests are
+// honoured, every mapping exists).
 enum { KIND_STEP = 0, KIND_ROLLOUT = 1 };
-int pick_lanes(const atacom_config& c, int kind) {
+int pick_lanes_raw(const atacom_config& c, int kind) {
     if (c.lanes_per_env == 1 || c.lanes_per_env == 2 || c.lanes_per_env == 4 || c.lanes_per_env == 8)
         return c.lanes_per_env;
     if (c.dtype == ATACOM_F64) return 1;
+    if (c.chart_mode == 1) return 1;
     if (c.env_id == ATACOM_ENV_IIWA) {
         const int upto8 = (kind == KIND_ROLLOUT) ? 8192 : 4096;
         return c.batch <= upto8 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));
@@ -83,6 +88,11 @@ int pick_lanes(const atacom_config& c, int kind) {
     if (c.env_id == ATACOM_ENV_PLANAR)
         return c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1);
     return 1;                                                              // circle: launch-bound either way
+}
+int pick_lanes(const atacom_config& c, int kind) {
+    const int l = pick_lanes_raw(c, kind);
+    if (c.dynamics_mode != 0) return l >= 4 ? 4 : 1;
+    return l;
 }
 
 // default initial state rows: [q, dq, puck(6)]
@@ -115,6 +125,21 @@ struct atacom_handle {
     double* partial_host;
 };
 
+// the stepping entry points of the handle's kernel variant (dynamics_mode x chart_mode)
+struct Stepper {
+    decltype(atacom::VariantOps::step) step;
+    decltype(atacom::VariantOps::rollout) rollout;
+    decltype(atacom::VariantOps::rollout_mlp) rollout_mlp;
+};
+static Stepper stepper(const atacom_handle* h) {
+    const atacom_config& c = h->cfg;
+    const atacom::VariantOps* v = nullptr;
+    if (c.dynamics_mode != 0) v = atacom::ops_iiwa_dyn_variant(c.dtype, c.chart_mode);
+    else if (c.chart_mode == 1) v = atacom::ops_chart(c.env_id, c.dtype);
+    if (v) return {v->step, v->rollout, v->rollout_mlp};
+    return {h->ops->step, h->ops->rollout, h->ops->rollout_mlp};
+}
+
 static int check_mlp(const atacom_handle* h, const atacom_mlp* net, const char* who) {
     const std::string w(who);
     if (net->struct_size != (int32_t)sizeof(atacom_mlp))
@@ -135,7 +160,7 @@ static int check_mlp(const atacom_handle* h, const atacom_mlp* net, const char* 
 extern "C" {
 
 const char* atacom_last_error(void) { return g_err.c_str(); }
-const char* atacom_version(void) { return "atacom_hip 0.1 (gfx950)"; }
+const char* atacom_version(void) { return "atacom_hip 0.3 (gfx950)"; }
 
 int atacom_get_dims(int32_t env_id, atacom_dims* out) {
     const atacom::EnvOps* ops = get_ops(env_id, ATACOM_F32);
@@ -162,6 +187,7 @@ int atacom_default_config(int32_t env_id, atacom_config* c) {
     c->action_penalty = 1e-3;    // env_hitting.py:10
     c->term_tol = 0.1;           // circle_terminated.py:13
     c->dynamics_mode = 0;
+    c->chart_mode = 0;
     if (env_id == ATACOM_ENV_CIRCLE || env_id == ATACOM_ENV_CIRCLE_EC || env_id == ATACOM_ENV_CIRCLE_T) {
         // circle_atacom.py:7-18 == circle_error_correction.py:8-21 (same constraints and gains)
         c->substeps = 1; c->horizon = 500; c->dt = 0.01; c->hold_q = 0;
@@ -212,8 +238,13 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
     if (cfg->lanes_per_env != 0 && cfg->lanes_per_env != 1 && cfg->lanes_per_env != 2 && cfg->lanes_per_env != 4 &&
         cfg->lanes_per_env != 8)
         return fail(ATACOM_E_INVALID, "atacom_create: lanes_per_env must be 0 (auto), 1, 2, 4 or 8");
-    if (cfg->dynamics_mode != 0 && !(cfg->dynamics_mode == 1 && cfg->env_id == ATACOM_ENV_IIWA))
-        return fail(ATACOM_E_INVALID, "atacom_create: dynamics_mode 1 (rigid body) exists for ATACOM_ENV_IIWA only");
+    if (cfg->dynamics_mode != 0 && !((cfg->dynamics_mode == 1 || cfg->dynamics_mode == 2) && cfg->env_id == ATACOM_ENV_IIWA))
+        return fail(ATACOM_E_INVALID, "atacom_create: dynamics_mode 1 / 2 (rigid body) exist for ATACOM_ENV_IIWA only");
+    if (cfg->chart_mode != 0 && cfg->chart_mode != 1)
+        return fail(ATACOM_E_INVALID, "atacom_create: chart_mode must be 0 (reference) or 1 (canonical)");
+    if (cfg->chart_mode == 1 && cfg->env_id != ATACOM_ENV_CIRCLE && cfg->env_id != ATACOM_ENV_PLANAR &&
+        cfg->env_id != ATACOM_ENV_IIWA)
+        return fail(ATACOM_E_INVALID, "atacom_create: chart_mode 1 needs an ATACOM environment (the E / T baselines have no chart)");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(ATACOM_E_INVALID, "atacom_create: no such device");
@@ -287,11 +318,20 @@ int atacom_step(atacom_handle* h, const void* d_action, void* d_obs, void* d_rew
     if (!d_action || !d_obs || !d_reward || !d_absorbing)
         return fail(ATACOM_E_INVALID, "atacom_step: d_action, d_obs, d_reward and d_absorbing are required");
     ON_DEVICE(h);
-    if (h->cfg.dynamics_mode == 1)
-        atacom::ops_iiwa_dyn(h->cfg.dtype)->step(h->cfg, pick_lanes(h->cfg, KIND_STEP), h->f, h->ip, d_action, d_obs, d_reward,
-                                                  d_absorbing, d_last, (hipStream_t)stream);
-    else
-    h->ops->step(h->cfg, pick_lanes(h->cfg, KIND_STEP), h->f, h->ip, d_action, d_obs, d_reward, d_absorbing, d_last, (hipStream_t)stream);
+    stepper(h).step(h->cfg, pick_lanes(h->cfg, KIND_STEP), h->f, h->ip, d_action, d_obs, d_reward, d_absorbing, d_last,
+                    nullptr, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+
+int atacom_step_masked(atacom_handle* h, const uint8_t* d_mask, const void* d_action, void* d_obs, void* d_reward,
+                       uint8_t* d_absorbing, uint8_t* d_last, void* stream) {
+    if (!h) return fail(ATACOM_E_INVALID, "atacom_step_masked: null handle");
+    if (!d_action || !d_obs || !d_reward || !d_absorbing)
+        return fail(ATACOM_E_INVALID, "atacom_step_masked: d_action, d_obs, d_reward and d_absorbing are required");
+    ON_DEVICE(h);
+    stepper(h).step(h->cfg, pick_lanes(h->cfg, KIND_STEP), h->f, h->ip, d_action, d_obs, d_reward, d_absorbing, d_last,
+                    d_mask, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
 }
@@ -303,9 +343,8 @@ int atacom_rollout(atacom_handle* h, int32_t n_steps, const void* d_actions, voi
     if (!d_actions || !d_obs || !d_reward || !d_absorbing || !d_last)
         return fail(ATACOM_E_INVALID, "atacom_rollout: all buffers except d_next_obs are required");
     ON_DEVICE(h);
-    (h->cfg.dynamics_mode == 1 ? atacom::ops_iiwa_dyn(h->cfg.dtype)->rollout : h->ops->rollout)(
-        h->cfg, pick_lanes(h->cfg, KIND_ROLLOUT), n_steps, h->f, h->ip, d_actions, d_obs, d_next_obs, d_reward, d_absorbing, d_last,
-        nullptr, 0, (hipStream_t)stream);
+    stepper(h).rollout(h->cfg, pick_lanes(h->cfg, KIND_ROLLOUT), n_steps, h->f, h->ip, d_actions, d_obs, d_next_obs, d_reward,
+                       d_absorbing, d_last, nullptr, 0, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
 }
@@ -319,10 +358,8 @@ int atacom_rollout_mlp(atacom_handle* h, int32_t n_steps, const atacom_mlp* net,
     if (vrc != ATACOM_OK) return vrc;
     if (!d_obs || !d_actions || !d_reward || !d_absorbing || !d_last)
         return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: all output buffers except d_next_obs are required");
-    if (h->cfg.dynamics_mode == 1)
-        return fail(ATACOM_E_UNSUPPORTED, "the policy rollout kernels have no rigid-body form (dynamics_mode 1)");
     ON_DEVICE(h);
-    const int rc = h->ops->rollout_mlp(h->cfg, pick_lanes(h->cfg, KIND_ROLLOUT), n_steps, *net, h->f, h->ip, d_noise, d_obs,
+    const int rc = stepper(h).rollout_mlp(h->cfg, pick_lanes(h->cfg, KIND_ROLLOUT), n_steps, *net, h->f, h->ip, d_noise, d_obs,
                                        d_next_obs, d_actions, d_reward, d_absorbing, d_last, nullptr, 0,
                                        (hipStream_t)stream);
     if (rc != ATACOM_OK)
@@ -341,18 +378,15 @@ int atacom_rollout_packed(atacom_handle* h, int32_t n_steps, const void* d_actio
     if (record_batch_stride < h->cfg.batch)
         return fail(ATACOM_E_INVALID, "atacom_rollout_packed: record_batch_stride must be >= batch");
     ON_DEVICE(h);
-    if (!d_actions && h->cfg.dynamics_mode == 1)
-        return fail(ATACOM_E_UNSUPPORTED, "the policy rollout kernels have no rigid-body form (dynamics_mode 1)");
     if (d_actions) {
-        (h->cfg.dynamics_mode == 1 ? atacom::ops_iiwa_dyn(h->cfg.dtype)->rollout : h->ops->rollout)(
-            h->cfg, pick_lanes(h->cfg, KIND_ROLLOUT), n_steps, h->f, h->ip, d_actions, nullptr, nullptr, nullptr, nullptr, nullptr,
-            d_records, record_batch_stride, (hipStream_t)stream);
+        stepper(h).rollout(h->cfg, pick_lanes(h->cfg, KIND_ROLLOUT), n_steps, h->f, h->ip, d_actions, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, d_records, record_batch_stride, (hipStream_t)stream);
     } else {
         const int vrc = check_mlp(h, net, "atacom_rollout_packed");
         if (vrc != ATACOM_OK) return vrc;
-        const int rc = h->ops->rollout_mlp(h->cfg, pick_lanes(h->cfg, KIND_ROLLOUT), n_steps, *net, h->f, h->ip, d_noise, nullptr, nullptr,
-                                           nullptr, nullptr, nullptr, nullptr, d_records, record_batch_stride,
-                                           (hipStream_t)stream);
+        const int rc = stepper(h).rollout_mlp(h->cfg, pick_lanes(h->cfg, KIND_ROLLOUT), n_steps, *net, h->f, h->ip, d_noise, nullptr,
+                                              nullptr, nullptr, nullptr, nullptr, nullptr, d_records, record_batch_stride,
+                                              (hipStream_t)stream);
         if (rc != ATACOM_OK)
             return fail(ATACOM_E_UNSUPPORTED, "atacom_rollout_packed: only planar / iiwa with hidden = 64 are compiled in");
     }
@@ -450,6 +484,17 @@ int atacom_nullspace(int32_t env_id, int32_t dtype, int32_t lanes_per_env, int32
     if (!ops) return fail(ATACOM_E_INVALID, "atacom_nullspace: unknown env_id / dtype");
     if (n <= 0 || !d_Jc) return fail(ATACOM_E_INVALID, "atacom_nullspace: n must be positive and d_Jc non-null");
     ops->nullspace(lanes_per_env, n, d_Jc, d_rhs, tol, d_x, d_null, d_rref, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+
+int atacom_canonical_mu(int32_t env_id, int32_t dtype, int32_t n, const void* d_A, const void* d_s, const void* d_y,
+                        const void* d_alpha, double tol, void* d_mu, void* stream) {
+    const atacom::VariantOps* v = (dtype == ATACOM_F32 || dtype == ATACOM_F64) ? atacom::ops_chart(env_id, dtype) : nullptr;
+    if (!v) return fail(ATACOM_E_INVALID, "atacom_canonical_mu: env_id must be circle / planar / iiwa, dtype f32 / f64");
+    if (n <= 0 || !d_A || !d_s || !d_y || !d_alpha || !d_mu)
+        return fail(ATACOM_E_INVALID, "atacom_canonical_mu: n must be positive and every buffer non-null");
+    v->chart_mu(n, d_A, d_s, d_y, d_alpha, tol, d_mu, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
 }

@@ -1,0 +1,412 @@
+// The opt-in canonical chart (cfg.chart_mode = 1; SURVEY.md section 7.3 H1 "null_mode = exact"): one sub-step's
+//     mu = -Jc^+ (psi + Kc c) + N alpha
+// through the slack structure of  Jc = [[a, 0], [A, diag(s)]]  instead of a factorisation of Jc.  Specification, derivation
+// and the relation to the reference's rref(tol) chart (atacom/atacom.py:123-133, null_space_coordinate.py:8-79):
+// oracle/canonical_chart.py -- this file is that recursion, decision by decision, in square-root form (see canonical_mu),
+// for one environment per lane.
+//
+//   M = I + sum_soft A_g^T A_g / s_g^2,  Gamma = M^-1   (dim_q x dim_q; the Gram matrix of the coordinate functionals on
+//                                                        the null space once every row has been imposed)
+//   rows that cannot go into M -- the equality row (s = 0) and stiff rows |s_g| < theta max|A_g| -- by one exact rank-one
+//   conditioning step each (the first stiff row keeps its slack velocity as a coordinate of the state: exact for every
+//   s >= 0);  x = minimum-norm solution
+//   chart: Cholesky of Gamma in joint order that skips a joint whose current diagonal ||P_S e_j||^2 <= tol^2; missing
+//   free coordinates go to the first slack columns that pass; N alpha falls out of the same recursion
+//   w_g = -(y_g + A_g u) / s_g with the true slack.
+// Cost for the iiwa task (12 x 17): ~1.3 k multiply-adds per sub-step against ~4.2 k for the LAPACK-basis chart.
+// Everything is straight-line code on compile-time indices; the data-dependent parts are selects, except two wave-uniform
+// ballots (stiff rows, slack coordinate) that skip work no lane of the wavefront needs.
+#pragma once
+#include "atacom_envs.h"
+#include "atacom_linalg.h"
+
+namespace atacom {
+
+template <typename T> struct chart_const {
+    static constexpr T THETA = T(3e-2);     // stiff-row threshold (oracle/canonical_chart.py: THETA)
+    static constexpr T TINY = T(1e-6);      // below this (relative) slack a row is an equality: w_g -> 0
+    static constexpr T FLOOR = std::is_same<T, float>::value ? T(1e-30) : T(1e-300);
+    static constexpr T REL = std::is_same<T, float>::value ? T(64 * 1.1920928955078125e-07) : T(64 * 2.220446049250313e-16);
+};
+
+// symmetric NQ x NQ matrix, lower triangle stored: sym(i, j) = sym(j, i)
+template <typename T, int N>
+struct SymMat {
+    T v[N * (N + 1) / 2];
+    __device__ __forceinline__ T& operator()(int i, int j) { return (i >= j) ? v[i * (i + 1) / 2 + j] : v[j * (j + 1) / 2 + i]; }
+    __device__ __forceinline__ const T& operator()(int i, int j) const {
+        return (i >= j) ? v[i * (i + 1) / 2 + j] : v[j * (j + 1) / 2 + i];
+    }
+};
+
+// L^-1 of the Cholesky factor of M (M = L L^T, lower triangle of M given): Gamma = M^-1 = Li^T Li.
+template <typename T, int N>
+__device__ __forceinline__ void chol_inverse_factor(const SymMat<T, N>& M, T (&Li)[N][N]) {
+    T L[N][N], inv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        T d = M(j, j);
+#pragma unroll
+        for (int k = 0; k < j; ++k) d = num<T>::fma(-L[j][k], L[j][k], d);
+        d = num<T>::max(d, chart_const<T>::FLOOR);
+        const T r = num<T>::rcp(num<T>::sqrt(d));
+        inv[j] = r;
+        L[j][j] = d * r;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            T a = M(i, j);
+#pragma unroll
+            for (int k = 0; k < j; ++k) a = num<T>::fma(-L[i][k], L[j][k], a);
+            L[i][j] = a * r;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        Li[j][j] = inv[j];
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            T a = T(0);
+#pragma unroll
+            for (int k = j; k < i; ++k) a = num<T>::fma(L[i][k], Li[k][j], a);
+            Li[i][j] = -a * inv[i];
+        }
+    }
+}
+
+// A (NC x NQ) = K J with the equality row (if any) first; arow[g] = max_c |A[NF + g][c]|; s: slacks; y = psi + Kc c;
+// alpha: the NK null coordinates.  mu (NN) = [joint accelerations | slack velocities].
+//
+// State of the recursion: x = (u, w_p), N1 = NQ + 1 -- w_p is the slack velocity of the FIRST stiff row p of the
+// environment, carried as a coordinate of its own (exact for every s_p >= 0, no division by s_p); inert (zero prior
+// variance) when the environment has no stiff row.
+//
+// SQUARE-ROOT FORM.  oracle/canonical_chart.py carries Gamma itself and takes the chart's pivots off its diagonal after
+// rank-one downdates; in float32 that loses them: a pivot near the tolerance, tol^2 = 2.5e-3, is what is left of O(1)
+// entries, so its relative error is eps / tol^2 and the coordinates of N alpha inherit it (measured on the iiwa task: 1 %
+// of the sub-steps off by > 3e-3 of max|mu|).  Here Gamma = R R^T is never formed: the recursion keeps the vectors
+// v_i = R^T e_i (one per coordinate of x; Gamma_ij = v_i . v_j), a functional p x becomes the vector w = sum_i p_i v_i, a
+// pivot is a SQUARED NORM |v_j|^2 (relative error eps / tol), and conditioning is the projection v_i -= w (w . v_i) / S
+// (Potter's square-root update when the row carries noise).  Same recursion, same decisions, in exact arithmetic the same
+// numbers; float32 vs the float64 specification: median 1.5e-7, 99.9 % below 1e-5 (profiles/r03_chart_float32.md).
+// Layout VT[k][i] = component k of v_i: both inner loops (g_i = v_i . w over k; v_i -= c g_i w) run over i with k fixed,
+// i.e. they are axpy-shaped and pack into v_pk_fma_f32 pairs.
+template <typename T, typename E>
+__device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T (&arow)[E::NG], const T (&s)[E::NG],
+                                             const T (&y)[E::NC], const T (&alpha)[E::NK], const T tol, T (&mu)[E::NN]) {
+    constexpr int NQ = E::NQ, NF = E::NF, NG = E::NG, NK = NQ - NF, N1 = NQ + 1;
+    static_assert(NF <= 1, "at most one equality row");
+    using CC = chart_const<T>;
+    const T tol2 = tol * tol;
+    // ---- metric of the soft rows
+    bool soft[NG], isp[NG];
+    T VT[N1][N1];                       // VT[k][i]: component k of v_i (i < NQ: joint i; i = NQ: the coordinate slack)
+    T x[N1];
+    {
+        SymMat<T, NQ> M;
+        T b[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            b[i] = T(0);
+#pragma unroll
+            for (int j = 0; j <= i; ++j) M(i, j) = (i == j) ? T(1) : T(0);
+        }
+        bool has_p = false;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int r = NF + g;
+            soft[g] = num<T>::abs(s[g]) >= CC::THETA * arow[g];
+            isp[g] = !soft[g] && !has_p;                            // the first stiff row: its slack is a coordinate
+            has_p = has_p || !soft[g];
+            const T om = soft[g] ? num<T>::rcp(s[g] * s[g]) : T(0);
+            T wa[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                if (E::jac_zero(r, i)) continue;
+                wa[i] = om * A[r][i];
+                b[i] = num<T>::fma(wa[i], y[r], b[i]);
+#pragma unroll
+                for (int j = 0; j <= i; ++j)
+                    if (!E::jac_zero(r, j)) M(i, j) = num<T>::fma(wa[i], A[r][j], M(i, j));
+            }
+        }
+        T Li[NQ][NQ];
+        chol_inverse_factor<T, NQ>(M, Li);
+        // Gamma = Li^T Li: v_i = column i of Li (zeros above the diagonal);  x = -Gamma b = -Li^T (Li b)
+        T z[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            T a = T(0);
+#pragma unroll
+            for (int j = 0; j <= k; ++j) a = num<T>::fma(Li[k][j], b[j], a);
+            z[k] = a;
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            T a = T(0);
+#pragma unroll
+            for (int k = i; k < NQ; ++k) a = num<T>::fma(Li[k][i], z[k], a);
+            x[i] = -a;
+        }
+        x[NQ] = T(0);
+#pragma unroll
+        for (int k = 0; k < N1; ++k)
+#pragma unroll
+            for (int i = 0; i < N1; ++i)
+                VT[k][i] = (k < NQ && i < NQ) ? ((k >= i) ? Li[k < NQ ? k : 0][i < NQ ? i : 0] : T(0))
+                                               : ((k == NQ && i == NQ && has_p) ? T(1) : T(0));
+    }
+    // the vector of a functional  f(x) = sum_i p_i x_i + cw x_w  and its products with every v_i
+    auto project = [&](const T (&w)[N1], const T cproj, T (&g)[N1]) {
+        // g_i = v_i . w;  v_i -= cproj g_i w
+#pragma unroll
+        for (int i = 0; i < N1; ++i) g[i] = T(0);
+#pragma unroll
+        for (int k = 0; k < N1; ++k)
+#pragma unroll
+            for (int i = 0; i < N1; ++i) g[i] = num<T>::fma(VT[k][i], w[k], g[i]);
+#pragma unroll
+        for (int k = 0; k < N1; ++k) {
+            const T wk = w[k] * cproj;
+#pragma unroll
+            for (int i = 0; i < N1; ++i) VT[k][i] = num<T>::fma(-g[i], wk, VT[k][i]);
+        }
+    };
+    // exact rank-one conditioning of the state on  (A_r, cw) . x + (noise of variance s2) = -yr
+    auto condition = [&](auto rc, const T cw, const T s2, const T yr, const bool on) {
+        constexpr int r = decltype(rc)::value;
+        T w[N1], g[N1];
+        T ww = T(0), e = -yr, nrm = num<T>::fma(cw, cw, s2);
+#pragma unroll
+        for (int k = 0; k < N1; ++k) {
+            T a = VT[k][NQ] * cw;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i)
+                if (!E::jac_zero(r, i)) a = num<T>::fma(VT[k][i], A[r][i], a);
+            w[k] = a;
+            ww = num<T>::fma(a, a, ww);
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            if (E::jac_zero(r, i)) continue;
+            e = num<T>::fma(-A[r][i], x[i], e);
+            nrm = num<T>::fma(A[r][i], A[r][i], nrm);
+        }
+        e = num<T>::fma(-cw, x[NQ], e);
+        const T S = s2 + ww;
+        // Gamma <= I: a row that has nothing left to say (vanishing, or dependent on rows imposed before) is dropped
+        const bool ok = on && (S > CC::REL * nrm);
+        const T iS = ok ? num<T>::rcp(S) : T(0);
+        // Potter: (I - c w w^T)^2 = I - w w^T / S  for  c = (1 / S) / (1 + sqrt(s2 / S))   (s2 = 0: the projection)
+        const T c = iS * num<T>::rcp(T(1) + num<T>::sqrt(s2 * iS));
+        project(w, c, g);
+        const T ce = e * iS;
+#pragma unroll
+        for (int i = 0; i < N1; ++i) x[i] = num<T>::fma(g[i], ce, x[i]);
+    };
+    if constexpr (NF == 1) condition(std::integral_constant<int, 0>{}, T(0), T(0), y[0], true);
+    static_for<0, NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if (__builtin_amdgcn_ballot_w64(!soft[g]) != 0ull)                  // wave-uniform: stiff rows are rare
+            condition(std::integral_constant<int, NF + g>{}, isp[g] ? s[g] : T(0), isp[g] ? T(0) : s[g] * s[g], y[NF + g],
+                      !soft[g]);
+    });
+    // ---- the chart: conditioning recursion over the joints with the skip rule
+    T U[N1];
+#pragma unroll
+    for (int i = 0; i < N1; ++i) U[i] = T(0);
+    int n_acc = 0;
+    static_for<0, NQ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        T w[N1], g[N1];
+        T dj = T(0);
+#pragma unroll
+        for (int k = 0; k < N1; ++k) { w[k] = VT[k][j]; dj = num<T>::fma(w[k], w[k], dj); }
+        const bool acc = (n_acc < NK) && (dj > tol2);
+        T tv = alpha[0];
+#pragma unroll
+        for (int i = 1; i < NK; ++i) tv = (n_acc == i) ? alpha[i] : tv;
+        const T inv = acc ? num<T>::rcp(dj) : T(0);
+        const T coef = (tv - U[j]) * inv;
+        project(w, inv, g);
+#pragma unroll
+        for (int i = 0; i < N1; ++i) U[i] = num<T>::fma(g[i], coef, U[i]);
+        n_acc += acc ? 1 : 0;
+    });
+    // ---- free coordinates still missing after the joints: slack columns, in column order, the first one that passes.
+    // The functional of slack column g on the extended state: f_g(x) = A_g u (then w_g = -f_g / s_g and
+    // ||P_S e_col||^2 = |vector of f_g|^2 / s_g^2), except for the coordinate slack p: f_p(x) = w_p itself.
+    bool sel[NG], tiny[NG];
+    T wtgt[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        sel[g] = false; wtgt[g] = T(0);
+        tiny[g] = !isp[g] && (num<T>::abs(s[g]) < CC::TINY * arow[g]);
+    }
+    bool done = false;
+    // (A) more than one missing (0.1 % of the iiwa sub-steps): the general step, any rank
+    if constexpr (NK >= 2) {
+#pragma unroll 1
+        for (int it = 0; it < NK - 1; ++it) {
+            const bool want = (n_acc < NK - 1) && !done;
+            if (__builtin_amdgcn_ballot_w64(want) == 0ull) break;
+            T tv = alpha[0];
+#pragma unroll
+            for (int i = 1; i < NK; ++i) tv = (n_acc == i) ? alpha[i] : tv;
+            T wsel[N1], vsel = T(0), rsel = T(0);
+#pragma unroll
+            for (int k = 0; k < N1; ++k) wsel[k] = T(0);
+            bool any = false, tnsel = false;
+            static_for<0, NG>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int r = NF + g;
+                T wg[N1], v = T(0), fu = T(0);
+#pragma unroll
+                for (int k = 0; k < N1; ++k) {
+                    T a = T(0);
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i)
+                        if (!E::jac_zero(r, i)) a = num<T>::fma(VT[k][i], A[r][i], a);
+                    wg[k] = isp[g] ? VT[k][NQ] : a;
+                    v = num<T>::fma(wg[k], wg[k], v);
+                }
+#pragma unroll
+                for (int i = 0; i < NQ; ++i)
+                    if (!E::jac_zero(r, i)) fu = num<T>::fma(A[r][i], U[i], fu);
+                fu = isp[g] ? U[NQ] : fu;
+                const T thr = tol2 * (isp[g] ? T(1) : s[g] * s[g]);
+                const bool pass = want && !sel[g] && (tiny[g] || (v > thr));
+                const bool take = pass && !any;
+                any = any || pass;
+#pragma unroll
+                for (int k = 0; k < N1; ++k) wsel[k] = take ? wg[k] : wsel[k];
+                vsel = take ? v : vsel;
+                // slack g: f_g(x) = -s_g target;  coordinate slack p: f_p(x) = +target
+                rsel = take ? (isp[g] ? fu - tv : num<T>::fma(s[g], tv, fu)) : rsel;
+                tnsel = take ? tiny[g] : tnsel;
+                wtgt[g] = take ? tv : wtgt[g];
+                sel[g] = sel[g] || take;
+            });
+            done = done || (want && !any);
+            const bool live = any && (vsel > T(0)) && !tnsel;
+            const T iv = live ? num<T>::rcp(vsel) : T(0);
+            T g[N1];
+            project(wsel, iv, g);
+            const T coef = rsel * iv;
+#pragma unroll
+            for (int i = 0; i < N1; ++i) U[i] = num<T>::fma(-g[i], coef, U[i]);
+            n_acc += any ? 1 : 0;
+        }
+    }
+    // (B) exactly one missing: S is one-dimensional, every v_i = beta_i dhat -- a scalar test per row
+    const bool need1 = (n_acc == NK - 1) && !done;
+    const T tv_last = alpha[NK - 1];
+    if (__builtin_amdgcn_ballot_w64(need1) != 0ull) {
+        T nrm2[N1];
+#pragma unroll
+        for (int i = 0; i < N1; ++i) nrm2[i] = T(0);
+#pragma unroll
+        for (int k = 0; k < N1; ++k)
+#pragma unroll
+            for (int i = 0; i < N1; ++i) nrm2[i] = num<T>::fma(VT[k][i], VT[k][i], nrm2[i]);
+        T dh[N1], sig = nrm2[0];                                    // the longest v_i: the best-conditioned direction
+#pragma unroll
+        for (int k = 0; k < N1; ++k) dh[k] = VT[k][0];
+#pragma unroll
+        for (int j = 1; j < N1; ++j) {
+            const bool better = nrm2[j] > sig;                      // first maximum, like np.argmax
+            sig = better ? nrm2[j] : sig;
+#pragma unroll
+            for (int k = 0; k < N1; ++k) dh[k] = better ? VT[k][j] : dh[k];
+        }
+        const T isd = (sig > T(0)) ? num<T>::rcp(num<T>::sqrt(sig)) : T(0);
+        T beta[N1];                                                 // Gamma = beta beta^T
+#pragma unroll
+        for (int i = 0; i < N1; ++i) beta[i] = T(0);
+#pragma unroll
+        for (int k = 0; k < N1; ++k) {
+            const T dk = dh[k] * isd;
+#pragma unroll
+            for (int i = 0; i < N1; ++i) beta[i] = num<T>::fma(VT[k][i], dk, beta[i]);
+        }
+        T fd[NG], res[NG], val[NG];
+        bool pick[NG];
+        bool any = false;
+        T vbest = T(-1);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int r = NF + g;
+            T a = T(0), fu = T(0);
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                if (E::jac_zero(r, i)) continue;
+                a = num<T>::fma(A[r][i], beta[i], a);
+                fu = num<T>::fma(A[r][i], U[i], fu);
+            }
+            fd[g] = isp[g] ? beta[NQ] : a;
+            res[g] = isp[g] ? U[NQ] - tv_last : num<T>::fma(s[g], tv_last, fu);
+            val[g] = fd[g] * fd[g];                                 // = f_g Gamma f_g^T
+            const T thr = tol2 * (isp[g] ? T(1) : s[g] * s[g]);
+            const bool pass = !sel[g] && (tiny[g] || (val[g] > thr));
+            pick[g] = need1 && pass && !any;
+            any = any || pass;
+            vbest = sel[g] ? vbest : num<T>::max(vbest, val[g]);
+        }
+        // nothing passed (a numerically rank-deficient remainder): the untaken column with the largest projection
+        bool taken = false;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const bool fb = need1 && !any && !taken && !sel[g] && (val[g] == vbest);
+            pick[g] = pick[g] || fb;
+            taken = taken || fb;
+        }
+        T fds = T(0), rs = T(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            fds = pick[g] ? (tiny[g] ? T(0) : fd[g]) : fds; rs = pick[g] ? res[g] : rs;
+            wtgt[g] = pick[g] ? tv_last : wtgt[g];
+            sel[g] = sel[g] || pick[g];
+        }
+        // x -= Gamma f^T (f x - target value) / (f Gamma f^T)  =  beta (...) / (f beta)
+        const T coef = (need1 && fds != T(0)) ? num<T>::div(rs, fds) : T(0);
+#pragma unroll
+        for (int i = 0; i < N1; ++i) U[i] = num<T>::fma(-beta[i], coef, U[i]);
+    }
+    // ---- assembly.  The equality row once more, exactly (rounding only): a u = -y_0, a U = 0
+    if constexpr (NF == 1) {
+        T aa = T(0), au = y[0], aU = T(0);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            if (E::jac_zero(0, i)) continue;
+            aa = num<T>::fma(A[0][i], A[0][i], aa);
+            au = num<T>::fma(A[0][i], x[i], au);
+            aU = num<T>::fma(A[0][i], U[i], aU);
+        }
+        const T iaa = (aa > T(0)) ? num<T>::rcp(aa) : T(0);
+        au *= iaa; aU *= iaa;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            if (E::jac_zero(0, i)) continue;
+            x[i] = num<T>::fma(-A[0][i], au, x[i]);
+            U[i] = num<T>::fma(-A[0][i], aU, U[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) mu[i] = x[i] + U[i];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int r = NF + g;
+        T wm = y[r], wa = T(0);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            if (E::jac_zero(r, i)) continue;
+            wm = num<T>::fma(A[r][i], x[i], wm);
+            wa = num<T>::fma(A[r][i], U[i], wa);
+        }
+        const T inv_s = (num<T>::abs(s[g]) >= CC::TINY * arow[g]) ? num<T>::rcp(s[g]) : T(0);
+        // a free slack coordinate takes its target itself; the coordinate slack is a component of the state
+        const T w = sel[g] ? num<T>::fma(-wm, inv_s, wtgt[g]) : -(wm + wa) * inv_s;
+        mu[NQ + g] = isp[g] ? x[NQ] + U[NQ] : w;
+    }
+}
+
+}  // namespace atacom

@@ -182,8 +182,9 @@ __device__ __forceinline__ void rnea9(const Chain9<T>& k, const T (&dq)[9], cons
 // leading block of the controlled joints, NR = 9 adds the coupling rows of the three servo joints (M[6..8][0..5], used
 // to put their accelerations on the right-hand side of the controlled joints' equation).  Composites are accumulated
 // from the tip (all nine bodies contribute).
+// dg (optional): the diagonal entries M_ii of the rows i >= NB (the servo joints' own inertias), dg[i - NB].
 template <typename T, int NB, int NR = NB>
-__device__ __forceinline__ void crba(const Chain9<T>& k, T (&Ml)[NR][NB]) {
+__device__ __forceinline__ void crba(const Chain9<T>& k, T (&Ml)[NR][NB], T* dg = nullptr) {
     static_assert(NR >= NB && NR <= 9, "");
     T vj[NB][3];                                            // velocity of joint j's body-fixed point at the world origin
 #pragma unroll
@@ -213,6 +214,10 @@ __device__ __forceinline__ void crba(const Chain9<T>& k, T (&Ml)[NR][NB]) {
             cross3(h, vi, t1);
 #pragma unroll
             for (int d = 0; d < 3; ++d) L[d] += t1[d];
+            if (dg && i >= NB) {
+                T v = num<T>::fma(k.a[i][0], L[0], num<T>::fma(k.a[i][1], L[1], k.a[i][2] * L[2]));
+                dg[i >= NB ? i - NB : 0] = num<T>::fma(vi[0], p[0], num<T>::fma(vi[1], p[1], num<T>::fma(vi[2], p[2], v)));
+            }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 if (j > i) continue;

@@ -1,44 +1,12 @@
-// Device code of the iiwa environment's rigid-body mode (row N4) and its stand-alone dynamics primitives, float32 and
-// float64 -- a translation unit of its own so that it compiles in parallel with the default kernels.
-// Mappings: one environment per lane (double, and float beyond 16384 environments) or per DPP quad (float).
+// Device code of the iiwa environment's rigid-body mode (row N4), float32, the reference's chart -- plus the servo-joint
+// state access and the stand-alone dynamics primitives in both precisions.  A translation unit of its own so that it
+// compiles in parallel with the default kernels (float64: atacom_iiwa_dyn_f64.hip; canonical chart: atacom_iiwa_dyn_chart.hip).
+// Mappings: one environment per lane or per DPP quad (Variant: the dynamics are computed redundantly by a group's lanes).
 #include "atacom_ops_impl.h"
 namespace atacom {
 template <typename T>
 struct Dyn {
     using E = Iiwa;
-    template <int LANES, bool HOLD>
-    static void launch_step(const atacom_config& c, void* f, int* ip, const void* act, void* obs, void* rew, uint8_t* ab,
-                            uint8_t* last, hipStream_t s) {
-        hipLaunchKernelGGL((k_step<T, E, LANES, HOLD, true>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)), dim3(BLOCK<LANES>),
-                           0, s, make_params<T>(c), (T*)f, ip, (const T*)act, (T*)obs, (T*)rew, ab, last);
-    }
-    static void step(const atacom_config& c, int lanes, void* f, int* ip, const void* act, void* obs, void* rew,
-                     uint8_t* ab, uint8_t* last, hipStream_t s) {
-        if (lanes >= 4) {
-            if (c.hold_q) launch_step<4, true>(c, f, ip, act, obs, rew, ab, last, s);
-            else launch_step<4, false>(c, f, ip, act, obs, rew, ab, last, s);
-        } else {
-            if (c.hold_q) launch_step<1, true>(c, f, ip, act, obs, rew, ab, last, s);
-            else launch_step<1, false>(c, f, ip, act, obs, rew, ab, last, s);
-        }
-    }
-    template <int LANES, bool HOLD>
-    static void launch_rollout(const atacom_config& c, int n_steps, void* f, int* ip, const void* acts, void* obs,
-                               void* nobs, void* rew, uint8_t* ab, uint8_t* last, void* rec, int rec_ld, hipStream_t s) {
-        hipLaunchKernelGGL((k_rollout<T, E, LANES, HOLD, true>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)),
-                           dim3(BLOCK<LANES>), 0, s, make_params<T>(c), n_steps, (T*)f, ip, (const T*)acts, (T*)obs,
-                           (T*)nobs, (T*)rew, ab, last, (T*)rec, rec_ld);
-    }
-    static void rollout(const atacom_config& c, int lanes, int n_steps, void* f, int* ip, const void* acts, void* obs,
-                        void* nobs, void* rew, uint8_t* ab, uint8_t* last, void* rec, int rec_ld, hipStream_t s) {
-        if (lanes >= 4) {
-            if (c.hold_q) launch_rollout<4, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
-            else launch_rollout<4, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
-        } else {
-            if (c.hold_q) launch_rollout<1, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
-            else launch_rollout<1, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
-        }
-    }
     static void get_aux(const atacom_config& c, const void* f, void* out, hipStream_t s) {
         hipLaunchKernelGGL((k_get_aux<T, E>), dim3(nblk(c.batch, 256)), dim3(256), 0, s, c.batch, (const T*)f, (T*)out);
     }
@@ -55,9 +23,16 @@ struct Dyn {
                            (const T*)tau6, (const T*)ddq_aux, use_damping, (T*)ddq6);
     }
     static const DynOps* table() {
-        static const DynOps ops = {&step, &rollout, &get_aux, &set_aux, &inverse_dynamics, &forward_dynamics};
+        static const DynOps ops = {&get_aux, &set_aux, &inverse_dynamics, &forward_dynamics};
         return &ops;
     }
 };
 const DynOps* ops_iiwa_dyn(int dtype) { return dtype == ATACOM_F64 ? Dyn<double>::table() : Dyn<float>::table(); }
+
+const VariantOps* ops_iiwa_dyn_f64();
+const VariantOps* ops_iiwa_dyn_chart(int dtype);
+const VariantOps* ops_iiwa_dyn_variant(int dtype, int chart_mode) {
+    if (chart_mode == 1) return ops_iiwa_dyn_chart(dtype);
+    return dtype == ATACOM_F64 ? ops_iiwa_dyn_f64() : Variant<float, Iiwa, true, 0>::table();
+}
 }  // namespace atacom

@@ -15,6 +15,7 @@
 #include "atacom_quad.h"
 #include "atacom_policy.h"
 #include "atacom_dynamics.h"
+#include "atacom_chart.h"
 
 namespace atacom {
 
@@ -235,11 +236,14 @@ __device__ __forceinline__ void reset_env(const Params<T>& P, const T* __restric
 
 // ------------------------------------------------------------------ row N4: one physics sub-step of the rigid-body mode
 // ddq (in: the truncated acceleration ATACOM asks for; out: what the arm does) -- DESIGN.md section 4a:
+//   servo joints (POSITION_CONTROL, env_base.py:64-70): velocity set-point v* = clip(0.1 (target - q) / dt, 1.5 v_max),
+//           targets env_single.py:137-185; the motor realises dds = (v* - dq) / dt as far as its torque allows:
+//           |M_ss,ii dds_i + h_s,i| <= URDF effort limit (iiwa_1.urdf:297,384,400; diagonal estimate of the motor torque);
 //   tau   = inverse dynamics of the nine-joint chain for [ddq, 0, 0, 0] at the SIMULATED state (acc_to_ctrl_action,
 //           iiwa_hit_atacom.py:58-63), saturated at the URDF effort limits (iiwa_1.urdf:74,112,149,186,223,260);
-//   servo joints (POSITION_CONTROL, env_base.py:64-70): velocity set-point v* = clip(0.1 (target - q) / dt, 1.5 v_max),
-//           targets env_single.py:137-185; their acceleration over the sub-step is prescribed, (v* - dq) / dt;
-//   ddq   = M_aa^-1 (tau - rnea_a(q, dq, [0; ddq_servo]) - D_a dq_a)       (hybrid forward dynamics, URDF joint damping).
+//           dynamics_mode 2: for [ddq, dds] -- the controller knows what the servo joints are about to do (feed-forward
+//           of their reaction on the arm; NOT what the reference computes);
+//   ddq   = M_aa^-1 (tau - rnea_a(q, dq, [0; dds]) - D_a dq_a)       (hybrid forward dynamics, URDF joint damping).
 template <typename T, typename E>
 __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<T, E>& st, T (&ddq)[E::NQ]) {
     static_assert(E::NQ == 6, "iiwa only");
@@ -259,8 +263,20 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
 #pragma unroll
     for (int i = 0; i < 9; ++i) zero9[i] = T(0);
     rnea9<T, true>(ch, dq9, zero9, h9);
-    T Ml[9][6];                                     // rows 0..5: M_cc (lower triangle); rows 6..8: M_sc = M_cs^T
-    crba<T, 6, 9>(ch, Ml);
+    T Ml[9][6], Mss[3];                             // rows 0..5: M_cc (lower triangle); rows 6..8: M_sc = M_cs^T
+    crba<T, 6, 9>(ch, Ml, Mss);
+    const T q6[6] = {st.q[0], st.q[1], st.q[2], st.q[3], st.q[4], st.q[5]};
+    const T tgt[3] = {joint7_target(q6, st.qx[0]), universal_target(ch.a[6], ch.a[7]), T(0)};
+    constexpr T vmax[3] = {T(1.5 * 2.356194490192345), T(1.5 * 3.1415926), T(1.5 * 3.1415926)};     // urdf:297,384,397
+    constexpr T effort_s[3] = {T(40), T(10), T(10)};                                                // urdf:297,384,400
+    T dds[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const T vstar = num<T>::min(num<T>::max(T(0.1) * (tgt[i] - st.qx[i]) / P.dt, -vmax[i]), vmax[i]);
+        const T lim = num<T>::div(num<T>::max(effort_s[i] - num<T>::abs(h9[6 + i]), T(0)), Mss[i]);
+        dds[i] = num<T>::min(num<T>::max((vstar - st.dqx[i]) / P.dt, -lim), lim);
+    }
+    const T ff = (P.dynamics_mode == 2) ? T(1) : T(0);
     constexpr T effort[6] = {T(320), T(320), T(176), T(176), T(110), T(40)};
     T tau[6];
 #pragma unroll
@@ -268,16 +284,9 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
         T t = h9[i];
 #pragma unroll
         for (int j = 0; j < 6; ++j) t = num<T>::fma((j <= i) ? Ml[i][j <= i ? j : 0] : Ml[j][i], ddq[j], t);
-        tau[i] = num<T>::min(num<T>::max(t, -effort[i]), effort[i]);
-    }
-    const T q6[6] = {st.q[0], st.q[1], st.q[2], st.q[3], st.q[4], st.q[5]};
-    const T tgt[3] = {joint7_target(q6, st.qx[0]), universal_target(ch.a[6], ch.a[7]), T(0)};
-    constexpr T vmax[3] = {T(1.5 * 2.356194490192345), T(1.5 * 3.1415926), T(1.5 * 3.1415926)};     // urdf:297,384,397
-    T vstar[3], dds[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        vstar[i] = num<T>::min(num<T>::max(T(0.1) * (tgt[i] - st.qx[i]) / P.dt, -vmax[i]), vmax[i]);
-        dds[i] = (vstar[i] - st.dqx[i]) / P.dt;
+        for (int s2 = 0; s2 < 3; ++s2) t = num<T>::fma(ff * Ml[6 + s2][i], dds[s2], t);
+        tau[i] = num<T>::min(num<T>::max(t, -effort[i]), effort[i]);
     }
     T rhs[6];
 #pragma unroll
@@ -291,14 +300,19 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
 #pragma unroll
     for (int i = 0; i < 6; ++i) ddq[i] = rhs[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { st.dqx[i] = vstar[i]; st.qx[i] = num<T>::fma(vstar[i], P.dt, st.qx[i]); }
+    for (int i = 0; i < 3; ++i) {
+        st.dqx[i] = num<T>::fma(dds[i], P.dt, st.dqx[i]);
+        st.qx[i] = num<T>::fma(st.dqx[i], P.dt, st.qx[i]);
+    }
 }
 
 // ------------------------------------------------------------------ one env step (A1, A2, A13-A15)
 // LANES = 1: one environment per lane (atacom_linalg.h).  LANES = 4: one environment per DPP quad -- the
 // null-space solve is column-split over the quad (atacom_quad.h), everything else is computed redundantly
 // (and bitwise identically) by the four lanes; `lq` is the lane's index in its quad.
-template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, bool HOIST_G0 = true>
+// CHART = 1: the opt-in canonical chart (atacom_chart.h) instead of the reference's LAPACK-basis + rref(tol) chart; every
+// lane of a group then computes the (small) solve redundantly, like everything else outside the group solver.
+template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, bool HOIST_G0 = true, int CHART = 0>
 __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st, const T (&act)[E::NK],
                                          StepOut<T>& out, const int lq) {
     constexpr int NQ = E::NQ, NF = E::NF, NG = E::NG, NC = E::NC, NN = E::NN, NK = E::NK;
@@ -342,7 +356,9 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                                // per row carried over the sub-steps instead of two)
     // hoist of the sub-step-invariant first reflector (see prepare): every mapping, ATACOM mode, held q / dq, and an
     // equality row on top of J_c (iiwa; the planar and circle J_c start with a slack-carrying row)
-    constexpr bool G0PRE = HOIST_G0 && HOLD && E::MODE == 0 && NF > 0 && NQ > 1;
+    constexpr bool CANON = CHART == 1 && E::MODE == 0;
+    constexpr bool G0PRE = HOIST_G0 && HOLD && E::MODE == 0 && NF > 0 && NQ > 1 && !CANON;
+    T arow[NG];                 // CANON: max |K J| of every inequality row (the scale its slack is compared with)
     T g0_d = T(0), g0_tau = T(0);
     constexpr int LGC = LANES > 1 ? LANES : 4;                  // lanes per environment of the group solver
     constexpr int SQ = split_slots(NN, LGC);
@@ -407,8 +423,18 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                     for (int c = 1; c < NQ; ++c) A[r][c] = num<T>::fma(-w, A[0][c], A[r][c]);
                 }
             }
+            if constexpr (CANON) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    T m = T(0);
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i)
+                        if (!E::jac_zero(NF + g, i)) m = num<T>::max(m, num<T>::abs(A[NF + g][i]));
+                    arow[g] = m;
+                }
+            }
             ATACOM_MARK("PRE_blend");
-            if (LANES > 1) {
+            if (LANES > 1 && !CANON) {
                 // this lane's columns of K J: a one-hot blend over the lane group (exact: the mask is 0 / 1 and the
                 // entries carry no -0 after the fma above).  Written as arithmetic on purpose -- a `lq == l ? ... : ...`
                 // select chain over all rows is turned into a divergent switch by the optimiser (measured: 350
@@ -447,7 +473,9 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
             // rhs = psi + Kc c,  c = fun + K J dq (+ s^2 / 2 on the g rows)
             y[r] = (r >= NF) ? num<T>::fma(T(0.5) * P.Kc[r] * sv, sv, yb[r]) : yb[r];
         }
-        if (LANES == 1 || E::MODE != 0) {
+        if constexpr (CANON) {
+            canonical_mu<T, E>(A, arow, st.s, y, alpha, P.rref_tol, mu);
+        } else if (LANES == 1 || E::MODE != 0) {
             T x[NN], nb[NN][NN - NC], nmu[NN];
             auto aget = [&](auto rc, auto cc) -> T {
                 constexpr int r = decltype(rc)::value, c = decltype(cc)::value;
@@ -595,13 +623,13 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
         const T gx = P.goal_x - st.puck[0], gy = P.goal_y - st.puck[1];
         const T gn = num<T>::sqrt(num<T>::fma(gx, gx, gy * gy));
         const T ign = num<T>::rcp(gn), idist = num<T>::rcp(dist);
-        T cosang = ((gx * ign) * (dx * idist)) + ((gy * ign) * (dy * idist));
+        T cosang = num<T>::fma(gx * ign, dx * idist, (gy * ign) * (dy * idist));      // (explicit contraction, as below)
         cosang = num<T>::min(num<T>::max(cosang, T(0)), T(1));
         const T r_app = num<T>::exp(T(-8) * (dist - T(0.08))) * cosang;
         const bool upd = !ab && (st.has_hit == 0);
         st.r_hit = upd ? r_app : st.r_hit;
-        T r = ab ? (goal ? T(80) : T(0)) : ((st.has_hit != 0) ? (T(1) + st.r_hit + st.vel_hit_x * T(0.1)) : r_app);
-        out.reward = r - P.action_penalty * num<T>::sqrt(anorm2);
+        T r = ab ? (goal ? T(80) : T(0)) : ((st.has_hit != 0) ? num<T>::fma(st.vel_hit_x, T(0.1), T(1) + st.r_hit) : r_app);
+        out.reward = num<T>::fma(-P.action_penalty, num<T>::sqrt(anorm2), r);     // explicit: the same contraction in every kernel
         out.absorbing = ab;
         // constraint statistics, atacom.py:201-205
         T cm = num<T>::abs(fun[0]);
@@ -619,11 +647,13 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
 }
 
 // ------------------------------------------------------------------ kernels
-template <typename T, typename E, int LANES, bool HOLD, bool DYN = false>
+// mask (nullable): environments whose byte is 0 sit the call out -- state, step counter and statistics untouched; they
+// report their current observation, reward 0, absorbing 0, last 0 (a vectorised Core's finished environments).
+template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, int CHART = 0>
 __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __restrict__ f, int* __restrict__ ip,
                                                const T* __restrict__ action, T* __restrict__ obs,
                                                T* __restrict__ reward, uint8_t* __restrict__ absorbing,
-                                               uint8_t* __restrict__ last) {
+                                               uint8_t* __restrict__ last, const uint8_t* __restrict__ mask) {
     // (kernarg preloading -- pointers and batch size first, -amdgpu-kernarg-preload-count=16 -- was tried: the waves no
     // longer wait for a scalar load before their first state loads, but the step time did not move (27.5 us both ways)
     // and the launch-bound circle kernel got slower, 7.4 -> 10.7 us: profiles/r02_lanes_vs_batch.md)
@@ -638,6 +668,15 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
 #endif
     EnvState<T, E> st;
     load_state<T, E>(f, ip, B, b, st);
+    if (mask && mask[b] == 0) {                // whole lane groups leave together (the mask is per environment)
+        if (lq == 0) {
+            write_obs<T, E>(P, st, obs + (size_t)b * E::OBS);
+            reward[b] = T(0);
+            absorbing[b] = 0;
+            if (last) last[b] = 0;
+        }
+        return;
+    }
     // the statistics accumulators are read up front with the rest of the state: a read-modify-write at the end
     // would make the store tail wait on loads queued behind ~60 stores (vmcnt counts both on gfx9-class hardware)
     const T ssum0 = pl<E>(f, L::SSUM, B, b), scmax0 = pl<E>(f, L::SCMAX, B, b);
@@ -653,7 +692,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     unsigned long long ts1;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1) : "v"(st.q[0]) : "memory");
 #endif
-    env_step<T, E, LANES, HOLD, DYN>(P, st, act, out, lq);
+    env_step<T, E, LANES, HOLD, DYN, true, CHART>(P, st, act, out, lq);
     ATACOM_MARK("STORE");
 #ifdef ATACOM_TIMESTAMPS
     unsigned long long ts2;
@@ -681,7 +720,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
 #endif
 }
 
-template <typename T, typename E, int LANES, bool HOLD, bool DYN = false>
+template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, int CHART = 0>
 __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int n_steps, T* __restrict__ f,
                                                   int* __restrict__ ip, const T* __restrict__ actions,
                                                   T* __restrict__ obs, T* __restrict__ next_obs,
@@ -725,7 +764,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
             }
         }
         StepOut<T> out;
-        env_step<T, E, LANES, HOLD, DYN>(P, st, act, out, lq);
+        env_step<T, E, LANES, HOLD, DYN, true, CHART>(P, st, act, out, lq);
         if (lq == 0) {
             if (rec) {
                 write_obs<T, E>(P, st, rrow + R::NOBS);
@@ -772,7 +811,7 @@ struct MlpPath {
     static constexpr int STAGE = (THREADS / WAVE) * LM::wave_stage(NB);   // floats of per-wave staging per workgroup
 };
 
-template <typename T, typename E, int LANES, bool HOLD, int H>
+template <typename T, typename E, int LANES, bool HOLD, int H, bool DYN = false, int CHART = 0>
 __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const MlpArgs<T> net, int n_steps,
                                                       T* __restrict__ f, int* __restrict__ ip,
                                                       const T* __restrict__ noise, T* __restrict__ obs,
@@ -805,6 +844,7 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
     const int erow = lane / LANES;                                             // own environment within the wavefront
     EnvState<T, E> st;
     load_state<T, E>(f, ip, B, b, st);
+    if constexpr (DYN) load_aux<T, E>(f, B, b, st);
     T ssum = T(0), scmax = pl<E>(f, L::SCMAX, B, b), sdq = pl<E>(f, L::SDQMAX, B, b);
 #pragma unroll 1
     for (int t = 0; t < n_steps; ++t) {
@@ -855,7 +895,7 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
         // (one environment per lane with the network's four GEMM blocks live is the one kernel at the edge of the register
         // file: with the G(0) hoist its spills move INTO the sub-step loop -- 59.6 -> 79.5 us per step, measured -- so it
         // keeps the un-hoisted solver)
-        env_step<T, E, LANES, HOLD, false, (LANES > 1)>(P, st, act, out, lq);
+        env_step<T, E, LANES, HOLD, DYN, (LANES > 1), CHART>(P, st, act, out, lq);
         if (lq == 0 && valid) {
             if (rec) {
                 write_obs<T, E>(P, st, rrow + R::NOBS);
@@ -880,6 +920,7 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
     pl<E>(f, L::SDQMAX, B, b) = sdq;
     pli(ip, L::I_CNT, b) += n_steps;
     store_state<T, E>(f, ip, B, b, st);
+    if constexpr (DYN) store_aux<T, E>(f, B, b, st);
 }
 
 template <typename T, typename E>
@@ -1184,6 +1225,36 @@ __global__ void __launch_bounds__(WAVE) k_nullspace_quad(int n, const T* __restr
             }
         }
     }
+}
+
+// the canonical chart as a stand-alone primitive (atacom_canonical_mu): A [n, NC, NQ], s [n, NG], y [n, NC], alpha [n, NK]
+template <typename T, typename E>
+__global__ void __launch_bounds__(WAVE) k_chart(int n, const T* __restrict__ Ain, const T* __restrict__ sin_,
+                                                const T* __restrict__ yin, const T* __restrict__ ain, T tol,
+                                                T* __restrict__ mu_o) {
+    constexpr int NQ = E::NQ, NF = E::NF, NG = E::NG, NC = E::NC, NN = E::NN, NK = NQ - NF;
+    const int b = blockIdx.x * WAVE + threadIdx.x;
+    if (b >= n) return;
+    T A[NC][NQ], arow[NG], s[NG], y[NC], alpha[NK], mu[NN];
+#pragma unroll
+    for (int r = 0; r < NC; ++r) {
+        y[r] = yin[(size_t)b * NC + r];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) A[r][i] = E::jac_zero(r, i) ? T(0) : Ain[((size_t)b * NC + r) * NQ + i];
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        s[g] = sin_[(size_t)b * NG + g];
+        T m = T(0);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) m = num<T>::max(m, num<T>::abs(A[NF + g][i]));
+        arow[g] = m;
+    }
+#pragma unroll
+    for (int k = 0; k < NK; ++k) alpha[k] = ain[(size_t)b * NK + k];
+    canonical_mu<T, E>(A, arow, s, y, alpha, tol, mu);
+#pragma unroll
+    for (int c = 0; c < NN; ++c) mu_o[(size_t)b * NN + c] = mu[c];
 }
 
 template <typename T, typename E>

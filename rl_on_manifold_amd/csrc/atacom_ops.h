@@ -12,8 +12,9 @@ struct EnvOps {
     int state_dim, init_dim, obs_dim, nq, nf, ng, nk;
     size_t elem;
     // lanes = 1, 2, 4 or 8 (lanes per environment)
+    // mask (nullable): environments with a zero byte sit the step out
     void (*step)(const atacom_config&, int lanes, void* f, int* ip, const void* act, void* obs, void* rew,
-                 uint8_t* ab, uint8_t* last, hipStream_t s);
+                 uint8_t* ab, uint8_t* last, const uint8_t* mask, hipStream_t s);
     void (*rollout)(const atacom_config&, int lanes, int n_steps, void* f, int* ip, const void* acts, void* obs,
                     void* nobs, void* rew, uint8_t* ab, uint8_t* last, void* rec, int rec_ld, hipStream_t s);
     // returns 0, or -3 if the (env, hidden size) combination is not compiled in
@@ -33,12 +34,26 @@ struct EnvOps {
                   hipStream_t s);
 };
 
-// Row N4: the rigid-body kernels of the iiwa environment live in their own translation unit (atacom_iiwa_dyn.hip)
-struct DynOps {
-    void (*step)(const atacom_config&, int lanes, void* f, int* ip, const void* act, void* obs, void* rew, uint8_t* ab,
-                 uint8_t* last, hipStream_t s);
+// The three stepping entry points of a kernel variant other than the default one (atacom_ops_impl.h: Variant)
+struct VariantOps {
+    void (*step)(const atacom_config&, int lanes, void* f, int* ip, const void* act, void* obs, void* rew,
+                 uint8_t* ab, uint8_t* last, const uint8_t* mask, hipStream_t s);
     void (*rollout)(const atacom_config&, int lanes, int n_steps, void* f, int* ip, const void* acts, void* obs,
                     void* nobs, void* rew, uint8_t* ab, uint8_t* last, void* rec, int rec_ld, hipStream_t s);
+    int (*rollout_mlp)(const atacom_config&, int lanes, int n_steps, const atacom_mlp& net, void* f, int* ip,
+                       const void* noise, void* obs, void* nobs, void* acts, void* rew, uint8_t* ab, uint8_t* last,
+                       void* rec, int rec_ld, hipStream_t s);
+    // the canonical chart as a primitive: A [n, c, q], s [n, g], y [n, c], alpha [n, k] -> mu [n, q + g]
+    void (*chart_mu)(int n, const void* A, const void* sl, const void* y, const void* alpha, double tol, void* mu,
+                     hipStream_t s);
+};
+// canonical-chart kernels (cfg.chart_mode = 1) of circle / planar / iiwa: atacom_chart.hip, atacom_chart_iiwa.hip
+const VariantOps* ops_chart(int env_id, int dtype);
+// Row N4: the rigid-body kernels of the iiwa environment (cfg.dynamics_mode = 1) with either chart: atacom_iiwa_dyn.hip
+const VariantOps* ops_iiwa_dyn_variant(int dtype, int chart_mode);
+
+// servo-joint state access and the stand-alone dynamics primitives (atacom_iiwa_dyn.hip)
+struct DynOps {
     void (*get_aux)(const atacom_config&, const void* f, void* out, hipStream_t s);
     void (*set_aux)(const atacom_config&, void* f, const void* in, hipStream_t s);
     void (*inverse_dynamics)(int n, const void* q, const void* dq, const void* ddq, void* tau, void* M, hipStream_t s);

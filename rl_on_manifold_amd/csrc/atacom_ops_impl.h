@@ -36,56 +36,45 @@ static Params<T> make_params(const atacom_config& c) {
 
 static inline int nblk(int n, int per) { return (n + per - 1) / per; }
 
-template <typename T, typename E>
-struct Ops {
-    using L = Planes<E>;
-    // kernel variants: LANES in {1, 2, 4, 8} x HOLD in {true, false}
-    template <int LANES, bool HOLD>
-    static void launch_step(const atacom_config& c, void* f, int* ip, const void* act, void* obs, void* rew,
-                            uint8_t* ab, uint8_t* last, hipStream_t s) {
-        hipLaunchKernelGGL((k_step<T, E, LANES, HOLD>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)), dim3(BLOCK<LANES>),
-                           0, s,
-                           make_params<T>(c), (T*)f, ip, (const T*)act, (T*)obs, (T*)rew, ab, last);
+// The step / rollout / policy-rollout launchers of one kernel VARIANT: kinematic or rigid-body dynamics (DYN, iiwa, row
+// N4), the reference's chart or the canonical one (CHART, atacom_chart.h).  Mappings: LANES in {1, 2, 4, 8}, x HOLD; the
+// rigid-body kernels exist for one environment per lane and per quad (the dynamics are computed redundantly by the lanes of
+// a group: wider groups buy nothing), atacom_capi.cpp clamps the mapping accordingly.
+template <typename T, typename E, bool DYN, int CHART>
+struct Variant {
+    static constexpr bool WIDE = !DYN;                 // lanes 2 and 8 instantiated
+    template <typename F>
+    static void with_mapping(int lanes, bool hold, F&& f) {
+        auto go = [&](auto lc) {
+            if (hold) f(lc, std::true_type{});
+            else f(lc, std::false_type{});
+        };
+        if constexpr (WIDE) {
+            if (lanes == 8) return go(std::integral_constant<int, 8>{});
+            if (lanes == 2) return go(std::integral_constant<int, 2>{});
+        }
+        if (lanes >= 4) return go(std::integral_constant<int, 4>{});
+        return go(std::integral_constant<int, 1>{});
     }
     static void step(const atacom_config& c, int lanes, void* f, int* ip, const void* act, void* obs, void* rew,
-                     uint8_t* ab, uint8_t* last, hipStream_t s) {
-        if (lanes == 8) {
-            if (c.hold_q) launch_step<8, true>(c, f, ip, act, obs, rew, ab, last, s);
-            else launch_step<8, false>(c, f, ip, act, obs, rew, ab, last, s);
-        } else if (lanes == 4) {
-            if (c.hold_q) launch_step<4, true>(c, f, ip, act, obs, rew, ab, last, s);
-            else launch_step<4, false>(c, f, ip, act, obs, rew, ab, last, s);
-        } else if (lanes == 2) {
-            if (c.hold_q) launch_step<2, true>(c, f, ip, act, obs, rew, ab, last, s);
-            else launch_step<2, false>(c, f, ip, act, obs, rew, ab, last, s);
-        } else {
-            if (c.hold_q) launch_step<1, true>(c, f, ip, act, obs, rew, ab, last, s);
-            else launch_step<1, false>(c, f, ip, act, obs, rew, ab, last, s);
-        }
-    }
-    template <int LANES, bool HOLD>
-    static void launch_rollout(const atacom_config& c, int n_steps, void* f, int* ip, const void* acts, void* obs,
-                               void* nobs, void* rew, uint8_t* ab, uint8_t* last, void* rec, int rec_ld, hipStream_t s) {
-        hipLaunchKernelGGL((k_rollout<T, E, LANES, HOLD>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)), dim3(BLOCK<LANES>),
-                           0, s,
-                           make_params<T>(c), n_steps, (T*)f, ip, (const T*)acts, (T*)obs, (T*)nobs, (T*)rew, ab, last,
-                           (T*)rec, rec_ld);
+                     uint8_t* ab, uint8_t* last, const uint8_t* mask, hipStream_t s) {
+        with_mapping(lanes, c.hold_q != 0, [&](auto lc, auto hc) {
+            constexpr int LANES = decltype(lc)::value;
+            constexpr bool HOLD = decltype(hc)::value;
+            hipLaunchKernelGGL((k_step<T, E, LANES, HOLD, DYN, CHART>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)),
+                               dim3(BLOCK<LANES>), 0, s, make_params<T>(c), (T*)f, ip, (const T*)act, (T*)obs, (T*)rew, ab,
+                               last, mask);
+        });
     }
     static void rollout(const atacom_config& c, int lanes, int n_steps, void* f, int* ip, const void* acts, void* obs,
                         void* nobs, void* rew, uint8_t* ab, uint8_t* last, void* rec, int rec_ld, hipStream_t s) {
-        if (lanes == 8) {
-            if (c.hold_q) launch_rollout<8, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
-            else launch_rollout<8, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
-        } else if (lanes == 4) {
-            if (c.hold_q) launch_rollout<4, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
-            else launch_rollout<4, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
-        } else if (lanes == 2) {
-            if (c.hold_q) launch_rollout<2, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
-            else launch_rollout<2, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
-        } else {
-            if (c.hold_q) launch_rollout<1, true>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
-            else launch_rollout<1, false>(c, n_steps, f, ip, acts, obs, nobs, rew, ab, last, rec, rec_ld, s);
-        }
+        with_mapping(lanes, c.hold_q != 0, [&](auto lc, auto hc) {
+            constexpr int LANES = decltype(lc)::value;
+            constexpr bool HOLD = decltype(hc)::value;
+            hipLaunchKernelGGL((k_rollout<T, E, LANES, HOLD, DYN, CHART>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)),
+                               dim3(BLOCK<LANES>), 0, s, make_params<T>(c), n_steps, (T*)f, ip, (const T*)acts, (T*)obs,
+                               (T*)nobs, (T*)rew, ab, last, (T*)rec, rec_ld);
+        });
     }
     template <int LANES, bool HOLD>
     static void launch_mlp(const atacom_config& c, int n_steps, const MlpArgs<T>& a, void* f, int* ip,
@@ -99,9 +88,9 @@ struct Ops {
         }
         const size_t lds_bytes = sizeof(T) * (((lds_floats + 3) / 4) * 4);
         constexpr int THREADS = MlpPath<T, E, LANES, H>::THREADS;
-        hipLaunchKernelGGL((k_rollout_mlp<T, E, LANES, HOLD, H>), dim3(nblk(c.batch * LANES, THREADS)), dim3(THREADS),
-                           lds_bytes, s, make_params<T>(c), a, n_steps, (T*)f, ip, (const T*)noise, (T*)obs, (T*)nobs,
-                           (T*)acts, (T*)rew, ab, last, (T*)rec, rec_ld);
+        hipLaunchKernelGGL((k_rollout_mlp<T, E, LANES, HOLD, H, DYN, CHART>), dim3(nblk(c.batch * LANES, THREADS)),
+                           dim3(THREADS), lds_bytes, s, make_params<T>(c), a, n_steps, (T*)f, ip, (const T*)noise, (T*)obs,
+                           (T*)nobs, (T*)acts, (T*)rew, ab, last, (T*)rec, rec_ld);
     }
     static int rollout_mlp(const atacom_config& c, int lanes, int n_steps, const atacom_mlp& net, void* f, int* ip,
                            const void* noise, void* obs, void* nobs, void* acts, void* rew, uint8_t* ab, uint8_t* last,
@@ -116,7 +105,7 @@ struct Ops {
         a.log_std_min = (T)net.log_std_min; a.log_std_max = (T)net.log_std_max; a.squash = net.squash;
         a.n_in = net.n_in; a.n_out = net.n_out; a.activation = net.activation;
         if constexpr (E::ID != 0) {
-            if constexpr (MlpPath<T, E, 8, 64>::MFMA) {
+            if constexpr (WIDE && MlpPath<T, E, 8, 64>::MFMA) {
                 // 8 lanes per environment: matrix-core form only (a wave = one GEMM block of 16 columns, 8 of them
                 // environments); the float64 parity build runs the quad form instead
                 if (lanes == 8) {
@@ -128,16 +117,36 @@ struct Ops {
             if (lanes >= 4) {
                 if (c.hold_q) launch_mlp<4, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
                 else launch_mlp<4, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
-            } else if (lanes == 2) {
-                if (c.hold_q) launch_mlp<2, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
-                else launch_mlp<2, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
-            } else {
-                if (c.hold_q) launch_mlp<1, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
-                else launch_mlp<1, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
+                return ATACOM_OK;
             }
+            if constexpr (WIDE) {
+                if (lanes == 2) {
+                    if (c.hold_q) launch_mlp<2, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
+                    else launch_mlp<2, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
+                    return ATACOM_OK;
+                }
+            }
+            if (c.hold_q) launch_mlp<1, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
+            else launch_mlp<1, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
         }
         return ATACOM_OK;
     }
+    static void chart_mu(int n, const void* A, const void* sl, const void* y, const void* alpha, double tol, void* mu,
+                         hipStream_t s) {
+        if constexpr (E::MODE == 0 && !DYN)
+            hipLaunchKernelGGL((k_chart<T, E>), dim3(nblk(n, WAVE)), dim3(WAVE), 0, s, n, (const T*)A, (const T*)sl,
+                               (const T*)y, (const T*)alpha, (T)tol, (T*)mu);
+    }
+    static const VariantOps* table() {
+        static const VariantOps ops = {&step, &rollout, &rollout_mlp, &chart_mu};
+        return &ops;
+    }
+};
+
+template <typename T, typename E>
+struct Ops {
+    using L = Planes<E>;
+    using V = Variant<T, E, false, 0>;
     static void reset(const atacom_config& c, void* f, int* ip, const uint8_t* mask, const void* init, void* obs,
                       hipStream_t s) {
         hipLaunchKernelGGL((k_reset<T, E>), dim3(nblk(c.batch, WAVE)), dim3(WAVE), 0, s, make_params<T>(c), (T*)f, ip,
@@ -184,7 +193,7 @@ struct Ops {
     }
     static const EnvOps* table() {
         static const EnvOps ops = {L::VALUES_PER_ENV, L::ICOUNT, L::STATE_DIM, L::INIT_DIM, E::OBS, E::NQ, E::NF, E::NG, E::NK,
-                                   sizeof(T), &step, &rollout, &rollout_mlp, &reset, &fill_init, &clear_stats, &stats,
+                                   sizeof(T), &V::step, &V::rollout, &V::rollout_mlp, &reset, &fill_init, &clear_stats, &stats,
                                    &get_state, &set_state, &nullspace, &terms};
         return &ops;
     }

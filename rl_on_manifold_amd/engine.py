@@ -40,7 +40,7 @@ class BatchedAtacomEnv:
     def __init__(self, env, batch, device='cuda:0', dtype=torch.float32, horizon=None, gamma=None, Kc=None,
                  time_step=None, n_intermediate_steps=None, action_penalty=None, auto_reset=False,
                  hold_q=None, bias_mode='reference', rref_tol=None, lanes_per_env=0, term_tol=None, random_init=False, seed=0,
-                 dynamics_mode='kinematic'):
+                 dynamics_mode='kinematic', chart_mode='reference'):
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.AtacomError("BatchedAtacomEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -78,8 +78,18 @@ class BatchedAtacomEnv:
         cfg.random_init = int(bool(random_init))     # device-side random reset (circle_base.py:36-42, env_hitting.py:24-25)
         cfg.seed = int(seed) & 0x7fffffff
         # 'kinematic': q'' integrates directly (default); 'rigid_body' (iiwa, row N4): inverse dynamics -> torque ->
-        # forward dynamics with the URDF inertias / damping and the joint-7 / universal-joint servos
-        cfg.dynamics_mode = {'kinematic': 0, 'rigid_body': 1}[dynamics_mode]
+        # forward dynamics with the URDF inertias / damping and the joint-7 / universal-joint servos;
+        # 'rigid_body_ff': the same with the servo joints' reaction fed forward into the inverse dynamics
+        modes = {'kinematic': 0, 'rigid_body': 1, 'rigid_body_ff': 2}
+        if dynamics_mode not in modes:
+            raise ValueError("dynamics_mode must be one of %s, got %r" % (sorted(modes), dynamics_mode))
+        cfg.dynamics_mode = modes[dynamics_mode]
+        # 'reference': LAPACK's null basis + rref(tol = 0.05), the reference's chart decision by decision (default);
+        # 'canonical' (opt-in): basis-independent chart, exact null basis on every state, ~3x cheaper
+        charts = {'reference': 0, 'canonical': 1}
+        if chart_mode not in charts:
+            raise ValueError("chart_mode must be one of %s, got %r" % (sorted(charts), chart_mode))
+        cfg.chart_mode = charts[chart_mode]
         d = _lib.get_dims(self.env_id)
         self.dims = {'q': d.dim_q, 'f': d.n_f, 'g': d.n_g, 'null': d.n_null, 'c': d.n_f + d.n_g}   # atacom.py:25-40
         self.obs_dim, self.state_dim, self.init_state_dim = d.obs_dim, d.state_dim, d.init_state_dim
@@ -97,6 +107,7 @@ class BatchedAtacomEnv:
         _lib.check(lib.atacom_create(C.byref(cfg), self._dev_index, C.byref(h)))
         self._h = h
         self._lib = lib
+        self._io_ok = set()
         B, k, D = self.batch, self.dims['null'], self.obs_dim
         self._obs = torch.empty((B, D), device=self.device, dtype=dtype)
         self._reward = torch.empty((B,), device=self.device, dtype=dtype)
@@ -163,7 +174,9 @@ class BatchedAtacomEnv:
         _lib.check(self._lib.atacom_reset(self._h, _ptr(m), _ptr(s), _ptr(obs), self._stream()))
         return obs
 
-    def step(self, actions):
+    def step(self, actions, mask=None):
+        """mask (optional, [B] bool / uint8): environments with a zero entry sit the call out ON THE DEVICE -- state, step
+        counter and statistics untouched, obs = their current observation, reward 0, flags False."""
         a = self._as_dev(actions, (self.batch, self.dims['null']))
         # fresh output tensors written by the kernel itself (the reference returns copies, atacom.py:115); the flags are
         # 0 / 1 bytes, so the bool tensors are reinterpreting views -- no copy or conversion kernel follows the step
@@ -172,14 +185,53 @@ class BatchedAtacomEnv:
         reward = torch.empty((B,), device=self.device, dtype=self.dtype)
         absorbing = torch.empty((B,), device=self.device, dtype=torch.uint8)
         last = torch.empty((B,), device=self.device, dtype=torch.uint8)
-        _lib.check(self._lib.atacom_step(self._h, _ptr(a), _ptr(obs), _ptr(reward), _ptr(absorbing), _ptr(last),
-                                          self._stream()))
+        if mask is None:
+            _lib.check(self._lib.atacom_step(self._h, _ptr(a), _ptr(obs), _ptr(reward), _ptr(absorbing), _ptr(last),
+                                              self._stream()))
+        else:
+            m = mask.view(torch.uint8) if (isinstance(mask, torch.Tensor) and mask.dtype == torch.bool
+                                           and mask.device == self.device and mask.is_contiguous()) \
+                else self._as_dev(mask, (B,), torch.uint8)
+            if tuple(m.shape) != (B,):
+                raise ValueError("expected a mask of shape (%d,), got %s" % (B, tuple(m.shape)))
+            _lib.check(self._lib.atacom_step_masked(self._h, _ptr(m), _ptr(a), _ptr(obs), _ptr(reward), _ptr(absorbing),
+                                                     _ptr(last), self._stream()))
         return obs, reward, absorbing.view(torch.bool), {'last': last.view(torch.bool)}
 
-    def step_into(self, actions, obs, reward, absorbing, last=None):
-        """Allocation-free variant of step(): caller-owned output tensors (uint8 for the flags)."""
-        _lib.check(self._lib.atacom_step(self._h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(absorbing),
-                                          _ptr(last), self._stream()))
+    def _check_io(self, t, shape, dtype, what):
+        """Raw-pointer entry points read whatever they are given: a float64, strided or host tensor would be read as
+        garbage.  Validated once per distinct tensor (keyed by storage, shape, dtype), so the steady state of a loop that
+        reuses its buffers pays one dict lookup per argument and allocates nothing."""
+        if t is None:
+            return
+        key = (what, t.data_ptr(), t.dtype, tuple(t.shape))
+        if key in self._io_ok:
+            return
+        if not isinstance(t, torch.Tensor) or t.device != self.device:
+            raise ValueError("%s must be a torch tensor on %s" % (what, self.device))
+        if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+            raise ValueError("%s must be a contiguous %s tensor of shape %s (got %s, %s%s)"
+                             % (what, dtype, tuple(shape), t.dtype, tuple(t.shape), '' if t.is_contiguous() else ', strided'))
+        if len(self._io_ok) > 4096:
+            self._io_ok.clear()
+        self._io_ok.add(key)
+
+    def step_into(self, actions, obs, reward, absorbing, last=None, mask=None):
+        """Allocation-free variant of step(): caller-owned output tensors (uint8 for the flags).  `mask` (uint8 [B],
+        optional): environments with a zero byte sit the call out on the device (atacom_step_masked)."""
+        B = self.batch
+        self._check_io(actions, (B, self.dims['null']), self.dtype, 'actions')
+        self._check_io(obs, (B, self.obs_dim), self.dtype, 'obs')
+        self._check_io(reward, (B,), self.dtype, 'reward')
+        self._check_io(absorbing, (B,), torch.uint8, 'absorbing')
+        self._check_io(last, (B,), torch.uint8, 'last')
+        if mask is None:
+            _lib.check(self._lib.atacom_step(self._h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(absorbing),
+                                              _ptr(last), self._stream()))
+        else:
+            self._check_io(mask, (B,), torch.uint8, 'mask')
+            _lib.check(self._lib.atacom_step_masked(self._h, _ptr(mask), _ptr(actions), _ptr(obs), _ptr(reward),
+                                                     _ptr(absorbing), _ptr(last), self._stream()))
 
     def rollout(self, actions, want_next_obs=True, out=None):
         """T env steps in one kernel launch.  actions [T, B, k] -> dict(obs, next_obs, reward, absorbing, last)."""
@@ -344,6 +396,8 @@ class GraphedRollout:
             self._body(policy, T)
         self._restore(saved, aux)                                           # the capture itself does not run the kernels,
                                                                             # but the warm-up did
+        # NOTE: the warm-up's real steps stay in the constraint statistics and (random_init) in the episode counters, which
+        # set_state does not cover: call get_constraints_logs() after construction if the log must start empty
 
     def _restore(self, saved, aux):
         self.env.set_state(saved)
@@ -465,12 +519,44 @@ def constraint_terms(env, q, dq, bias_mode='reference'):
     return fun, J, b
 
 
+def _check_same(ref, shape, **tensors):
+    """Every tensor: a ROCm tensor of `shape` with ref's dtype and device (the primitives take raw pointers)."""
+    if ref.dtype not in (torch.float32, torch.float64) or not ref.is_cuda:
+        raise ValueError("expected float32 / float64 ROCm tensors")
+    for name, t in tensors.items():
+        if not isinstance(t, torch.Tensor) or tuple(t.shape) != tuple(shape) or t.dtype != ref.dtype or t.device != ref.device:
+            raise ValueError("%s must be a %s tensor of shape %s on %s (got %s %s on %s)"
+                             % (name, ref.dtype, tuple(shape), ref.device, getattr(t, 'dtype', type(t)),
+                                tuple(getattr(t, 'shape', ())), getattr(t, 'device', None)))
+
+
+def canonical_mu(env, A, s, y, alpha, tol=0.05):
+    """The canonical chart (chart_mode='canonical') as a primitive on the GPU: A [n, c, dim_q] = K J (equality row first),
+    s [n, n_g], y [n, c] = psi + Kc c, alpha [n, k]  ->  mu [n, dim_q + n_g] = -Jc^+ y + N alpha."""
+    lib = _lib.load()
+    env_id = _ENV_IDS[env] if isinstance(env, str) else int(env)
+    d = _lib.get_dims(env_id)
+    n, c, nq, ng, k = A.shape[0], d.n_f + d.n_g, d.dim_q, d.n_g, d.dim_q - d.n_f
+    _check_same(A, (n, c, nq), A=A)
+    _check_same(A, (n, ng), s=s)
+    _check_same(A, (n, c), y=y)
+    _check_same(A, (n, k), alpha=alpha)
+    A, s, y, alpha = A.contiguous(), s.contiguous(), y.contiguous(), alpha.contiguous()
+    dt = {torch.float32: _lib.F32, torch.float64: _lib.F64}[A.dtype]
+    mu = torch.empty((n, nq + ng), device=A.device, dtype=A.dtype)
+    stream = C.c_void_p(torch.cuda.current_stream(A.device).cuda_stream)
+    with torch.cuda.device(A.device):
+        _lib.check(lib.atacom_canonical_mu(env_id, dt, n, _ptr(A), _ptr(s), _ptr(y), _ptr(alpha), float(tol), _ptr(mu), stream))
+    return mu
+
+
 def inverse_dynamics(q, dq, ddq, want_mass_matrix=False):
     """Row N4 primitive: tau = M(q) ddq + C(q, dq) dq + g(q) of the nine-joint iiwa + striker chain on the GPU
     (what the reference asks PyBullet for, iiwa_hit_atacom.py:58-63).  q, dq, ddq [n, 9]; returns tau [n, 9]
     (and M [n, 9, 9])."""
     lib = _lib.load()
     n = q.shape[0]
+    _check_same(q, (n, 9), q=q, dq=dq, ddq=ddq)
     q, dq, ddq = q.contiguous(), dq.contiguous(), ddq.contiguous()
     dt = {torch.float32: _lib.F32, torch.float64: _lib.F64}[q.dtype]
     tau = torch.empty((n, 9), device=q.device, dtype=q.dtype)
@@ -486,6 +572,10 @@ def forward_dynamics(q, dq, tau6, ddq_aux=None, damping=True):
     ddq_aux [n, 3] (None = at rest)."""
     lib = _lib.load()
     n = q.shape[0]
+    _check_same(q, (n, 9), q=q, dq=dq)
+    _check_same(q, (n, 6), tau6=tau6)
+    if ddq_aux is not None:
+        _check_same(q, (n, 3), ddq_aux=ddq_aux)
     q, dq, tau6 = q.contiguous(), dq.contiguous(), tau6.contiguous()
     aux = None if ddq_aux is None else ddq_aux.contiguous()
     dt = {torch.float32: _lib.F32, torch.float64: _lib.F64}[q.dtype]

@@ -1,0 +1,95 @@
+"""Inputs for the canonical-chart tests (CPU and GPU): (A, s, y, alpha) systems sampled from oracle rollouts of the three
+tasks -- the states the engine actually visits, chart switches included -- plus hand-made degenerate ones."""
+import numpy as np
+
+from oracle import atacom_batched as ob
+from oracle import atacom_scalar as osc
+
+IIWA_INIT_Q = np.array([0.0, 0.7135214629060707, 0.0, -0.5024756033561426, 0.0, 1.9256631778550268])
+SPECS = {'circle': osc.circle_spec, 'planar': osc.planar_spec, 'iiwa': osc.iiwa_spec}
+_CACHE = {}
+
+
+def init_q(name, B, rng, sigma=0.05):
+    q0 = {'circle': np.array([-1.0, 0.0]), 'planar': ob.robots.PLANAR_INIT_Q, 'iiwa': IIWA_INIT_Q}[name]
+    return q0 + (rng.normal(0, sigma, (B, len(q0))) if name != 'circle' else 0.0)
+
+
+def rollout_systems(name, B=256, T=40, seed=0, stride=3):
+    """Every `stride`-th (Jc, rhs, N) the reference-chart oracle factorised during a B x T rollout, as
+    dict(A [n, c, q], s [n, g], y [n, c], Jc [n, c, q + g], Nr [n, q + g, k] = the reference's rref'd basis,
+         skipped [n] = the reference took its tolerance branch)."""
+    key = (name, B, T, seed, stride)
+    if key in _CACHE:
+        return _CACHE[key]
+    spec = SPECS[name]()
+    rng = np.random.default_rng(seed)
+    env = ob.BatchedAtacomEnv(spec, B, init_q=init_q(name, B, rng))
+    store = []
+    orig = ob.bidiag_solve_null
+
+    def hook(Jc, rhs, k, cond=None):
+        x, N = orig(Jc, rhs, k, cond)
+        store.append((Jc.copy(), rhs.copy(), N.copy()))
+        return x, N
+    ob.bidiag_solve_null = hook
+    try:
+        for t in range(T):
+            a = rng.uniform(-1.2, 1.2, (B, spec.n_null))
+            _, _, ab, _ = env.step(a)
+            last = ab | (env.t >= spec.horizon)
+            if last.any():
+                env.reset(last)
+    finally:
+        ob.bidiag_solve_null = orig
+    Jc = np.concatenate([s_[0] for s_ in store])[::stride]
+    rhs = np.concatenate([s_[1] for s_ in store])[::stride]
+    N = np.concatenate([s_[2] for s_ in store])[::stride]
+    nq, nf, ng = spec.dim_q, spec.n_f, spec.n_g
+    skipped = np.zeros(len(Jc), dtype=bool)
+    Nr = ob.rref_tol(N, spec.rref_tol, skipped=skipped)
+    out = {'A': Jc[:, :, :nq].copy(), 's': Jc[:, nf + np.arange(ng), nq + np.arange(ng)].copy(), 'y': rhs, 'Jc': Jc,
+           'Nr': Nr, 'skipped': skipped, 'spec': spec}
+    _CACHE[key] = out
+    return out
+
+
+def degenerate_systems(name, seed=1):
+    """Hand-made hard cases on top of rollout systems: slacks at exactly zero, tiny slacks (1e-9 ... 1e-2 of the row),
+    several at once, a vanishing equality row, the pair of mutually negative table rows both nearly active."""
+    base = rollout_systems(name)
+    spec = base['spec']
+    rng = np.random.default_rng(seed)
+    n = 96
+    idx = rng.choice(len(base['A']), n, replace=False)
+    A, s, y = base['A'][idx].copy(), base['s'][idx].copy(), base['y'][idx].copy()
+    ng, nf = spec.n_g, spec.n_f
+    arow = np.abs(A[:, nf:, :]).max(2)
+    for i in range(n):
+        kind = i % 6
+        g = rng.integers(ng)
+        if kind == 0:
+            s[i, g] = 0.0
+        elif kind == 1:
+            s[i, g] = arow[i, g] * 10.0 ** rng.uniform(-9, -2) * rng.choice([-1, 1])
+        elif kind == 2:
+            gs = rng.choice(ng, min(3, ng), replace=False)
+            s[i, gs] = arow[i, gs] * 10.0 ** rng.uniform(-6, -2, len(gs))
+        elif kind == 3 and nf:
+            A[i, 0, :] = 0.0                      # the straight-up pose: the equality row vanishes
+        elif kind == 4 and ng > 2:
+            # the table rows "-y_w - b" and "y_w - b" are exact negatives of each other in both arm tasks (rows 1, 2 of
+            # the inequality block): both slacks small -> two dependent near-equalities
+            s[i, 1:3] = arow[i, 1:3] * 10.0 ** rng.uniform(-4, -2, 2)
+        elif kind == 5:
+            s[i, rng.choice(ng, 2, replace=False) if ng > 1 else 0] = 0.0      # two slacks at zero (an infeasible reset)
+    return {'A': A, 's': s, 'y': y, 'spec': spec, 'kind': np.arange(n) % 6}
+
+
+def jc_of(A, s, nf):
+    n, nc, nq = A.shape
+    ng = s.shape[1]
+    Jc = np.zeros((n, nc, nq + ng))
+    Jc[:, :, :nq] = A
+    Jc[:, nf + np.arange(ng), nq + np.arange(ng)] = s
+    return Jc

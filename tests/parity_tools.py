@@ -46,7 +46,7 @@ def slice_env(o, idx):
 
 def perturbed(o, scale, rng, fields=('q', 'dq', 's', 'puck')):
     p = slice_env(o, np.arange(o.B))
-    for k in ('decision_margin', 'contact_margin', 'cond_number'):
+    for k in ('decision_margin', 'contact_margin', 'cond_number', 'chart_skipped', 'chart_info', 'chart_default'):
         p.__dict__.pop(k, None)
     for f in fields:
         arr = getattr(p, f)
@@ -86,7 +86,7 @@ class SensitivityRecorder:
         """Oracle side of one sample (independent of the device, so a test parametrised over kernel mappings prepares
         once and compares many times).  Call BEFORE the oracle env `o` is stepped; returns the oracle outputs."""
         snap = slice_env(o, np.arange(o.B))
-        for k in ('decision_margin', 'contact_margin', 'cond_number'):
+        for k in ('decision_margin', 'contact_margin', 'cond_number', 'chart_skipped', 'chart_info', 'chart_default'):
             snap.__dict__.pop(k, None)
         base = self.step_fn(slice_env(snap, np.arange(o.B)), inputs)
         self.snaps.append(snap); self.inputs.append(inputs); self.base.append(base)

@@ -93,19 +93,22 @@ def _aux(o):
     return np.concatenate([o.qx, o.dqx], 1)
 
 
-@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('mode', ['rigid_body', 'rigid_body_ff'])
+@pytest.mark.parametrize('lanes', [1, 4, 8])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
-def test_rigid_body_env_step_against_oracle(dt, lanes):
-    """dynamics_mode = 'rigid_body': the whole env step (ATACOM projection, inverse dynamics, effort saturation, servo
+def test_rigid_body_env_step_against_oracle(dt, lanes, mode):
+    """dynamics_mode = 'rigid_body' / 'rigid_body_ff': the whole env step (ATACOM projection, inverse dynamics, effort saturation, servo
     joints, hybrid forward dynamics, integration) vs the oracle, teacher-forced incl. the servo-joint state."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_gpu_parity import _full_state
     from parity_tools import SensitivityRecorder
     from rl_on_manifold_amd import BatchedAtacomEnv
-    spec = osc.iiwa_spec(dynamics_mode=1)
+    spec = osc.iiwa_spec(dynamics_mode={'rigid_body': 1, 'rigid_body_ff': 2}[mode])
     B, T = 256, 30
-    env = BatchedAtacomEnv('iiwa', B, device=DEV, dtype=DT[dt], lanes_per_env=lanes, dynamics_mode='rigid_body')
+    env = BatchedAtacomEnv('iiwa', B, device=DEV, dtype=DT[dt], lanes_per_env=lanes, dynamics_mode=mode)
+    # the rigid-body kernels exist per lane and per quad: a wider request maps down, and the handle says so
+    assert env.lanes_per_env == env.rollout_lanes_per_env == min(lanes, 4)
     rng = np.random.default_rng(3)
     o = ob.BatchedAtacomEnv(spec, B, init_q=IIWA_INIT_Q + rng.normal(0, 0.05, (B, 6)))
 
@@ -134,6 +137,8 @@ def test_rigid_body_env_step_against_oracle(dt, lanes):
     if dt == 'f32':
         print(rec.finish('rigid-body step lanes %d' % lanes))
     # and the mode is not a no-op: the kinematic engine lands elsewhere
+    if mode != 'rigid_body':
+        return
     kin = BatchedAtacomEnv('iiwa', B, device=DEV, dtype=DT[dt], lanes_per_env=lanes)
     kin.set_state(_full_state(kin, o)); env.set_state(_full_state(env, o)); env.set_aux_state(_aux(o))
     a = rng.uniform(-1, 1, (B, 5))
@@ -156,5 +161,80 @@ def test_rigid_body_rollout_equals_steps_and_keeps_the_constraints():
     assert torch.allclose(e1.get_aux_state(), e2.get_aux_state(), atol=2e-5)
     c_avg, c_max, c_dq = e1.get_constraints_logs()
     assert c_max < 0.02 and c_dq < 0.0
+    assert e1.lanes_per_env == 4 and e1.rollout_lanes_per_env == 4          # B = 512 would pick 8 lanes: clamped, and said so
     with pytest.raises(Exception):
         BatchedAtacomEnv('planar', 8, device=DEV, dynamics_mode='rigid_body')
+
+
+def _config4_free_run(mode, B, T, seed):
+    """Free-running rigid-body engine and oracle from the feasible initial states of BASELINE config 4."""
+    import bench
+    from rl_on_manifold_amd import BatchedAtacomEnv
+    gen = torch.Generator(device=DEV); gen.manual_seed(seed)
+    init = bench.feasible_init('iiwa', B, torch.device(DEV), gen)[0]
+    acts = torch.rand((T, B, 5), device=DEV, generator=gen) * 2 - 1
+    env = BatchedAtacomEnv('iiwa', B, device=DEV, dynamics_mode=mode, auto_reset=True)
+    env.reset(state=init)
+    out = env.rollout(acts)
+    q6_min = float(out['next_obs'][:, :, 11].abs().min())
+    dev = env.get_constraints_logs()
+    i64 = init.double().cpu().numpy()
+    spec = osc.iiwa_spec(dynamics_mode={'rigid_body': 1, 'rigid_body_ff': 2}[mode])
+    o = ob.BatchedAtacomEnv(spec, B, init_q=i64[:, :6], init_dq=i64[:, 6:12], init_puck=i64[:, 12:18])
+    a64 = acts.double().cpu().numpy()
+    for t in range(T):
+        _, _, ab, _ = o.step(a64[t])
+        last = ab | (o.t >= o.spec.horizon)
+        if last.any():
+            o.reset(last)
+    return dev, o.get_constraints_logs(), q6_min
+
+
+def test_rigid_body_free_running_velocity_guarantee():
+    """Where the rigid-body mode breaks ATACOM's velocity guarantee, and the mode that keeps it.
+    1024 config-4 environments x 120 steps, free-running, HIP float32 and oracle float64 on identical input; the run
+    reaches |q6| < 0.1, where joints 5 and 7 align and the reference's joint-7 set-point (env_single.py:137-170) flips by
+    pi / 2 from sub-step to sub-step: the servo then swings at +-1.5 v_max, 1700 rad/s^2, and the reaction M_57 dds throws
+    joint 5 about -- the URDF effort limits (40 Nm against ~7 Nm needed) do not bind.
+      rigid_body    : the reference's inverse dynamics (zeros for the servo joints): c_dq_max > 0 is the MODEL's, the same
+                      in both precisions, and bounded by the 1.5 v_max velocity clamp;
+      rigid_body_ff : servo accelerations fed forward: c_dq_max <= 1e-3."""
+    B, T = 1024, 120
+    (d1, o1, q6a), (d2, o2, q6b) = _config4_free_run('rigid_body', B, T, 7), _config4_free_run('rigid_body_ff', B, T, 7)
+    print('rigid_body    device %s oracle %s min|q6| %.3f' % (np.round(d1, 4), np.round(o1, 4), q6a))
+    print('rigid_body_ff device %s oracle %s min|q6| %.3f' % (np.round(d2, 4), np.round(o2, 4), q6b))
+    assert q6a < 0.1 and q6b < 0.1
+    for d, o in ((d1, o1), (d2, o2)):
+        assert o[1] / 1.5 <= d[1] <= 1.5 * o[1] and abs(d[0] - o[0]) <= 0.15 * o[0], (d, o)
+    vmax = osc.iiwa_spec().vel_max.max()
+    assert d1[2] <= 0.5 * vmax + 1e-3 and o1[2] <= 0.5 * vmax + 1e-9             # the 1.5 x clamp
+    assert d2[2] <= 1e-3 and o2[2] <= 1e-3, (d2, o2)
+
+
+def test_policy_rollout_in_rigid_body_mode(golden):
+    """Rows N2 + N4 together: the actor network evaluated inside the rigid-body rollout kernel (lane and quad mappings)
+    == the host evaluating the same network step by step on the rigid-body step kernel."""
+    from rl_on_manifold_amd import BatchedAtacomEnv, MlpPolicy
+    B, T = 160, 10
+    gw = torch.Generator().manual_seed(1)
+    W = [torch.randn(64, 18, generator=gw) * 0.2, torch.randn(64, generator=gw) * 0.1, torch.randn(64, 64, generator=gw) * 0.1,
+         torch.randn(64, generator=gw) * 0.1, torch.randn(5, 64, generator=gw) * 0.1, torch.zeros(5)]
+    pol = MlpPolicy(*W, std=torch.full((5,), 0.3))
+    Wd = [w.to(DEV) for w in W]
+    for lanes in (1, 4):
+        env = BatchedAtacomEnv('iiwa', B, device=DEV, dynamics_mode='rigid_body', lanes_per_env=lanes)
+        g = torch.Generator(device=DEV).manual_seed(4)
+        eps = torch.randn((T, B, 5), device=DEV, generator=g)
+        st, aux = env.get_state().clone(), env.get_aux_state().clone()
+        out = env.rollout_policy(pol, T, noise=eps)
+        assert torch.isfinite(out['reward']).all()
+        env.set_state(st); env.set_aux_state(aux)
+        obs = out['obs'][0]
+        for t in range(T):
+            h = torch.relu(obs @ Wd[0].T + Wd[1])
+            h = torch.relu(h @ Wd[2].T + Wd[3])
+            a = h @ Wd[4].T + Wd[5] + 0.3 * eps[t]
+            assert torch.allclose(a, out['action'][t], atol=2e-4), (lanes, t)
+            obs, r, ab, info = env.step(out['action'][t])
+            assert torch.allclose(obs, out['next_obs'][t], atol=1e-4), (lanes, t, float((obs - out['next_obs'][t]).abs().max()))
+        assert float(env.get_aux_state().abs().max()) > 1e-4
