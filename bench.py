@@ -19,11 +19,15 @@ each block's time = MAX over ranks; blocks are repeated until >= --min-time seco
 block is reported (a single 20-step block is 0.6 ms -- one scheduler hiccup would move the number by 10 %).
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      HBM view: algorithmic bytes per launch / mean kernel time (HIP events on the launch stream)
-  roofline_valu fp32 vector-ALU view of the same kernel (this workload is ALU/latency bound)
+  roofline      the BINDING roof of the step kernel: fp32 vector ALU (bound "valu_f32": algorithmic FLOPs per launch /
+                mean kernel time from HIP events on the launch stream; this workload sits at 130 FLOP/B, far right of
+                the ridge -- SURVEY.md section 8d); `traffic` = measured HBM bytes per launch
+  roofline_hbm  the HBM view of the same kernel (algorithmic bytes per launch / the same kernel time)
   collection    config 5's collection phase: rollout_packed(120 steps, one launch) + the one all-gather of the
                 packed records (ms, bytes, GB/s per rank)
-  secondary     circle-4096 and planar-8192 (BASELINE configs 2 and 3) with their own rooflines (N = 1 only)
+  secondary     circle-4096 and planar-8192 (BASELINE configs 2 and 3) with their own rooflines; the iiwa headline
+                workload through the Python step() surface, with the opt-in canonical chart (chart_mode 1, its own
+                roofline against ITS algorithmic FLOPs), and in the rigid-body modes (N = 1 only)
   cpu_baseline  the float64 oracle timed on this box's host cores on bounded samples (rank 0, N = 1 only):
                 scalar reference-shaped (1 core and all cores) and batched numpy; + the oracle's constraint
                 statistics on 256 of the very same initial states and actions next to the device's
@@ -69,6 +73,32 @@ def algorithmic_flops(env):
     f += 6 * M + 14 * nq                                              # rhs assembly, slack, truncation, integration
     per_sub = f
     fk = {'circle': 20, 'planar': 150, 'iiwa': 1500}[env]             # constraint terms + post-step kinematics
+    return sub * per_sub + 2 * fk + 4 * M * nq
+
+
+# structural non-zeros per row of K J (rl_on_manifold_amd/csrc/atacom_envs.h: jac_zero), equality row first
+ROW_NNZ = {'circle': [2, 2], 'planar': [3, 3, 3, 1, 1, 1], 'iiwa': [6, 6, 6, 6, 2, 6, 1, 1, 1, 1, 1, 1]}
+
+
+def algorithmic_flops_canonical(env):
+    """FLOPs per env-step of the canonical chart as the kernel runs it (rl_on_manifold_amd/csrc/atacom_chart.h, square-root
+    recursion on the extended state N1 = dim_q + 1; FMA = 2; the slack stage counted once -- it runs in 14 % of the iiwa
+    sub-steps; stiff-row steps, selects and compares not counted)."""
+    M, N, K, nq, sub = SHAPES[env]
+    nf = M - (N - nq)
+    nnz = ROW_NNZ[env]
+    g_rows = nnz[nf:]
+    n1 = nq + 1
+    f = sum(z * (z + 1) // 2 + 2 * z for z in g_rows)                  # M, b
+    f += nq ** 3 // 3 + nq * nq                                       # Cholesky, its inverse
+    f += nq * (nq + 1)                                                # x = -Gamma b
+    cond = lambda z: z * n1 + n1 + 2 * n1 * n1 + z + n1               # noqa: E731  vector, norm, project, residual, x
+    f += cond(nnz[0]) if nf else 0
+    f += nq * (n1 + 2 * n1 * n1 + n1)                                 # joint recursion
+    f += 3 * n1 * n1 + 2 * sum(g_rows) + 3 * len(g_rows)              # slack stage (B)
+    f += 4 * nq + 2 * sum(g_rows) + 3 * len(g_rows)                   # equality row once more, slack velocities
+    per_sub = 2 * f + 6 * M + 14 * nq
+    fk = {'circle': 20, 'planar': 150, 'iiwa': 1500}[env]
     return sub * per_sub + 2 * fk + 4 * M * nq
 
 
@@ -127,10 +157,10 @@ def feasible_init(name, B, dev, gen, sigma=0.05):
     return init, 1.0 - kept_of / drawn
 
 
-def make_env(name, B, dev, gen, lanes=0):
+def make_env(name, B, dev, gen, lanes=0, **kw):
     import torch
     from rl_on_manifold_amd import BatchedAtacomEnv
-    env = BatchedAtacomEnv(name, B, device=dev, dtype=torch.float32, auto_reset=True, lanes_per_env=lanes)
+    env = BatchedAtacomEnv(name, B, device=dev, dtype=torch.float32, auto_reset=True, lanes_per_env=lanes, **kw)
     init, rej = None, 0.0
     if name != 'circle':
         init, rej = feasible_init(name, B, dev, gen)
@@ -216,16 +246,19 @@ def graphed_step_us(env, actions, n=20, reps=30):
     return (time.perf_counter() - t0) / (reps * n) * 1e6
 
 
-def roofline_objects(name, B, kern_ms, traffic=None):
+def roofline_objects(name, B, kern_ms, traffic=None, chart='reference'):
+    """(roofline, roofline_hbm): the binding roof first -- fp32 vector ALU -- then the HBM view of the same kernel."""
     algo_bytes = ALGO_BYTES[name] * B
-    flops = algorithmic_flops(name) * B
+    flops = (algorithmic_flops_canonical(name) if chart == 'canonical' else algorithmic_flops(name)) * B
     gbs = algo_bytes / (kern_ms * 1e-3) / 1e9
     tf = flops / (kern_ms * 1e-3) / 1e12
-    return ({'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
-             'traffic': traffic, 'algorithmic_bytes_per_launch': algo_bytes, 'kernel_ms': kern_ms,
-             'note': 'workload is fp32-VALU / dependent-issue bound, see roofline_valu and DESIGN.md'},
-            {'bound': 'valu_f32', 'achieved': tf, 'peak': VALU_F32_PEAK_TF, 'unit': 'TFLOP/s',
-             'frac': tf / VALU_F32_PEAK_TF, 'algorithmic_flops_per_launch': flops})
+    return ({'bound': 'valu_f32', 'achieved': tf, 'peak': VALU_F32_PEAK_TF, 'unit': 'TFLOP/s',
+             'frac': tf / VALU_F32_PEAK_TF, 'traffic': traffic, 'algorithmic_flops_per_launch': flops,
+             'kernel_ms': kern_ms,
+             'note': 'fp32 vector ALU is the binding roof (130 FLOP/B, ridge at 20); traffic = measured HBM bytes per '
+                     'launch (FETCH_SIZE + WRITE_SIZE, profiles/traffic_*.json) next to roofline_hbm.algorithmic_bytes_per_launch'},
+            {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+             'traffic': traffic, 'algorithmic_bytes_per_launch': algo_bytes, 'kernel_ms': kern_ms})
 
 
 def main():
@@ -236,10 +269,13 @@ def main():
     ap.add_argument('--env', default='iiwa')
     ap.add_argument('--batch', type=int, default=8192)
     ap.add_argument('--lanes', type=int, default=0, help='kernel mapping: 0 = library policy, else lanes per env')
-    ap.add_argument('--min-time', type=float, default=0.5, help='keep timing K-step blocks until this many seconds')
+    ap.add_argument('--chart-mode', default='reference', choices=['reference', 'canonical'],
+                    help="chart of the HEADLINE engine (default: the reference's; 'canonical' is the opt-in mode, also "
+                         "timed as a secondary record of the default run)")
+    ap.add_argument('--min-time', type=float, default=2.0, help='keep timing K-step blocks until this many seconds')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true')
-    ap.add_argument('--cpu-seconds', type=float, default=8.0, help='budget of each scalar CPU-baseline leg')
+    ap.add_argument('--cpu-seconds', type=float, default=4.0, help='budget of each scalar CPU-baseline leg')
     args = ap.parse_args()
 
     env_world = os.environ.get('WORLD_SIZE')
@@ -293,7 +329,7 @@ def main():
     B, K, W = args.batch, args.steps, args.warmup
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    env, init, rejected = make_env(args.env, B, dev, gen, args.lanes)
+    env, init, rejected = make_env(args.env, B, dev, gen, args.lanes, chart_mode=args.chart_mode)
     k, D = env.dims['null'], env.obs_dim
     n_pool = 64
     actions = torch.rand((n_pool, B, k), device=dev, generator=gen) * 2 - 1
@@ -379,13 +415,8 @@ def main():
     result = None
     if rank == 0:
         traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic_%s.json' % args.env)
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get('hbm_bytes_per_launch')
-            except Exception:  # noqa: BLE001
-                traffic = None
-        roof, roof_valu = roofline_objects(args.env, B, kern_ms, traffic)
+        traffic = measured_traffic(args.env, args.chart_mode) if B == {'circle': 4096}.get(args.env, 8192) else None
+        roof, roof_hbm = roofline_objects(args.env, B, kern_ms, traffic, args.chart_mode)
         result = {
             'metric': 'env-steps/sec', 'value': world * B * K / elapsed, 'unit': 'env-steps/s', 'n_gpus': world,
             'steps': K, 'warmup': W, 'ms_per_step': elapsed / K * 1e3, 'higher_is_better': True, 'scaling': 'weak',
@@ -394,6 +425,7 @@ def main():
                        'batch_per_gpu': B, 'global_batch': B * world,
                        'lanes_per_env_requested': int(env.cfg.lanes_per_env), 'lanes_per_env': env.lanes_per_env, 'rollout_lanes_per_env': env.rollout_lanes_per_env, 'substeps': int(env.cfg.substeps),
                        'horizon': int(env.cfg.horizon), 'path': 'atacom_step (1 launch / step) via C ABI',
+                       'chart_mode': args.chart_mode,
                        'init': 'q_init + N(0, 0.05^2), one correction step, rejected unless all g < 0 and |f| < 1e-3 '
                                '(%.1f %% of draws rejected); puck uniform in the hit range' % (100 * rejected)
                                if args.env != 'circle' else 'half fixed reset point, half random valid states',
@@ -404,7 +436,7 @@ def main():
             'max_abs_c': c_max, 'c_avg': c_avg, 'c_dq_max': c_dq_max,
             'collection': collection,
             'policy_rollout_kernel_env_steps_per_s_per_gpu': pol_rate,
-            'roofline': roof, 'roofline_valu': roof_valu,
+            'roofline': roof, 'roofline_hbm': roof_hbm,
         }
     # the engine of the headline run is no longer needed; secondary workloads and the CPU legs are N = 1 extras
     if world == 1 and rank == 0:
@@ -418,6 +450,15 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+def measured_traffic(name, chart='reference'):
+    """HBM bytes per launch of the step kernel at the BASELINE batch, from the committed counter passes."""
+    tpath = os.path.join(ROOT, 'profiles', 'traffic_%s%s.json' % (name, '_canonical' if chart == 'canonical' else ''))
+    try:
+        return json.load(open(tpath)).get('hbm_bytes_per_launch')
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def rccl_selfgather(env, rec, dev, reps=5):
@@ -467,7 +508,7 @@ def secondary_records(dev, gen, K, W, sync_all, max_over_ranks):
         env, _, _ = make_env(name, B, dev, gen)
         k = env.dims['null']
         acts = torch.rand((64, B, k), device=dev, generator=gen) * 2 - 1
-        secs, kern_ms = time_steps(env, acts, K, W, 0.2, sync_all, max_over_ranks)
+        secs, kern_ms = time_steps(env, acts, K, W, 0.7, sync_all, max_over_ranks)
         el = float(np.median(secs))
         c_avg, c_max, c_dq = env.get_constraints_logs()
         racts = torch.rand((120, B, k), device=dev, generator=gen) * 2 - 1
@@ -479,24 +520,28 @@ def secondary_records(dev, gen, K, W, sync_all, max_over_ranks):
         torch.cuda.synchronize(dev)
         roll = 5 * 120 * B / (time.perf_counter() - t0)
         g_us = graphed_step_us(env, acts)
-        roof, roof_valu = roofline_objects(name, B, kern_ms)
+        roof, roof_hbm = roofline_objects(name, B, kern_ms, measured_traffic(name))
         out.append({'workload': WORKLOAD[name] + ', batch %d' % B, 'value': B * K / el, 'unit': 'env-steps/s',
                     'ms_per_step': el / K * 1e3, 'blocks': len(secs), 'max_abs_c': c_max, 'c_avg': c_avg,
                     'c_dq_max': c_dq, 'rollout_kernel_env_steps_per_s': roll,
                     'hip_graph_20_steps_us_per_step': g_us, 'roofline': roof,
-                    'roofline_valu': roof_valu})
+                    'roofline_hbm': roof_hbm})
         env.close()
     # the iiwa headline workload through the allocating Python surface (step(): clones + bool conversion per call), and
     # in the opt-in rigid-body mode (row N4)
     import rl_on_manifold_amd as pkg
-    for label, kw in (('python step() surface', {}), ('rigid-body mode (dynamics_mode = 1)', {'dynamics_mode': 'rigid_body'})):
+    for label, kw in (('python step() surface', {}),
+                      ('canonical chart (chart_mode = 1, opt-in)', {'chart_mode': 'canonical'}),
+                      ('rigid-body mode (dynamics_mode = 1)', {'dynamics_mode': 'rigid_body'}),
+                      ('rigid-body mode with servo feed-forward (dynamics_mode = 2)', {'dynamics_mode': 'rigid_body_ff'})):
         B = 8192
         env = pkg.BatchedAtacomEnv('iiwa', B, device=dev, dtype=torch.float32, auto_reset=True, **kw)
         init, _ = feasible_init('iiwa', B, dev, gen)
         env.reset(state=init)
         acts = torch.rand((64, B, 5), device=dev, generator=gen) * 2 - 1
+        kern_ms = None
         if kw:
-            secs, kern_ms = time_steps(env, acts, K, W, 0.2, sync_all, max_over_ranks)
+            secs, kern_ms = time_steps(env, acts, K, W, 0.7, sync_all, max_over_ranks)
             el = float(np.median(secs))
         else:
             for i in range(W):
@@ -509,8 +554,21 @@ def secondary_records(dev, gen, K, W, sync_all, max_over_ranks):
             torch.cuda.synchronize(dev)
             el = (time.perf_counter() - t0) * K / n
         c_avg, c_max, c_dq = env.get_constraints_logs()
-        out.append({'workload': 'IiwaAirHockey env 7H, batch 8192, ' + label, 'value': B * K / el, 'unit': 'env-steps/s',
-                    'ms_per_step': el / K * 1e3, 'max_abs_c': c_max, 'c_avg': c_avg, 'c_dq_max': c_dq})
+        rec = {'workload': 'IiwaAirHockey env 7H, batch 8192, ' + label, 'value': B * K / el, 'unit': 'env-steps/s',
+               'ms_per_step': el / K * 1e3, 'max_abs_c': c_max, 'c_avg': c_avg, 'c_dq_max': c_dq,
+               'lanes_per_env': env.lanes_per_env, 'rollout_lanes_per_env': env.rollout_lanes_per_env}
+        if 'chart_mode' in kw:
+            racts = torch.rand((120, B, 5), device=dev, generator=gen) * 2 - 1
+            r_ = env.rollout_packed(actions=racts)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                env.rollout_packed(actions=racts, out=r_)
+            torch.cuda.synchronize(dev)
+            rec['rollout_kernel_env_steps_per_s'] = 5 * 120 * B / (time.perf_counter() - t0)
+            rec['roofline'], rec['roofline_hbm'] = roofline_objects('iiwa', B, kern_ms, measured_traffic('iiwa', 'canonical'),
+                                                                    'canonical')
+        out.append(rec)
         env.close()
     return out
 

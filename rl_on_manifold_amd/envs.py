@@ -221,175 +221,3 @@ class VectorizedAtacomEnv:
 
     def get_constraints_logs(self):
         return self._engine.get_constraints_logs()
-
-
-class CircleEnvAtacom(_Facade):
-    _env_name = 'circle'
-
-    def __init__(self, horizon=500, gamma=0.99, random_init=False, Kc=100, time_step=0.01, device='cuda:0',
-                 dtype=torch.float32):
-        self.random_init = random_init
-        self._make(horizon=horizon, gamma=gamma, Kc=Kc, time_step=time_step, device=device, dtype=dtype)
-
-    def reset(self, state=None):
-        if state is None:
-            if self.random_init:                       # circle_base.py:36-42
-                y = np.random.uniform(-0.5, 1)
-                x = np.sqrt(1 - y ** 2) * np.sign(np.random.uniform(-1, 1))
-                dx = np.random.uniform(-1, 1)
-                dy = -x * dx / y
-                v = np.array([dx, dy])
-                v = v / np.linalg.norm(v) * np.random.uniform(0, 1)
-                state = np.array([x, y, v[0], v[1]])
-            else:
-                state = np.array([-1.0, 0.0, 0.0, 0.0])   # :44
-        else:
-            state = np.asarray(state, dtype=np.float64)
-            # the reference's guard, verbatim in behaviour (circle_base.py:46-49)
-            if not (abs(state[0] ** 2 + state[1] ** 2 - 1) < 1e-6
-                    and abs(state[0] * state[2] - state[1] * state[3]) < 1e-6):
-                raise ValueError("Can not reset to the state: ", state)
-        self.state = self._engine.reset(state=state.reshape(1, 4))[0].cpu().numpy().astype(np.float64)
-        return self.state
-
-
-class CircleEnvErrorCorrection(CircleEnvAtacom):
-    """Baseline 'E' (circle_error_correction.py:7-21): the action is the 2-d acceleration, only the error-correction
-    term -Jc^+ Kc c is added.  Same constructor as the reference."""
-    _env_name = 'circle_ec'
-
-    def __init__(self, horizon=500, gamma=0.99, random_init=False, Kc=100., time_step=0.01, device='cuda:0',
-                 dtype=torch.float32):
-        super().__init__(horizon=horizon, gamma=gamma, random_init=random_init, Kc=Kc, time_step=time_step,
-                         device=device, dtype=dtype)
-
-
-class CircleEnvTerminated(CircleEnvAtacom):
-    """Baseline 'T' (circle_terminated.py:8-29): unconstrained 2-d acceleration control, the episode ends with reward
-    -100 as soon as a constraint value exceeds `tol`.  Same constructor as the reference."""
-    _env_name = 'circle_t'
-
-    def __init__(self, time_step=0.01, horizon=500, gamma=0.99, random_init=False, tol=0.1, device='cuda:0',
-                 dtype=torch.float32):
-        self.random_init = random_init
-        self._make(horizon=horizon, gamma=gamma, time_step=time_step, term_tol=tol, device=device, dtype=dtype)
-
-
-class _AirHockeyFacade(_Facade):
-    def _init_common(self, task, gamma, horizon, timestep, n_intermediate_steps, env_noise, obs_noise, obs_delay,
-                     Kc, random_init, action_penalty, device, dtype):
-        if task != 'H':
-            raise NotImplementedError("only the hitting task 'H' is on the hot path (BASELINE.json configs)")
-        if env_noise or obs_noise or obs_delay:
-            raise NotImplementedError("domain randomisation (env_noise / obs_noise / obs_delay) is out of scope")
-        self.random_init = random_init
-        self._make(horizon=horizon, gamma=gamma, Kc=Kc, time_step=timestep,
-                   n_intermediate_steps=n_intermediate_steps, action_penalty=action_penalty, device=device,
-                   dtype=dtype)
-        st = self._engine.get_state()[0].cpu().numpy()
-        nq = self.dims['q']
-        self._init_q = st[:nq].astype(np.float64)
-
-    def reset(self, state=None):
-        nq = self.dims['q']
-        if state is not None:
-            state = np.asarray(state, dtype=np.float64)
-        else:
-            if self.random_init:                       # env_hitting.py:24-25
-                puck_pos = np.random.rand(2) * (HIT_RANGE[:, 1] - HIT_RANGE[:, 0]) + HIT_RANGE[:, 0]
-            else:                                      # :27
-                puck_pos = np.mean(HIT_RANGE, axis=1)
-            state = np.concatenate([self._init_q, np.zeros(nq), puck_pos, np.zeros(4)])
-        self.state = self._engine.reset(state=state.reshape(1, -1))[0].cpu().numpy().astype(np.float64)
-        return self.state
-
-
-class AirHockeyPlanarAtacom(_AirHockeyFacade):
-    _env_name = 'planar'
-
-    def __init__(self, task='H', gamma=0.99, horizon=120, timestep=1 / 240., n_intermediate_steps=4,
-                 debug_gui=False, env_noise=False, obs_noise=False, obs_delay=False, Kc=240., random_init=False,
-                 action_penalty=1e-3, device='cuda:0', dtype=torch.float32):
-        self._init_common(task, gamma, horizon, timestep, n_intermediate_steps, env_noise, obs_noise, obs_delay,
-                          Kc, random_init, action_penalty, device, dtype)
-
-
-class AirHockeyIiwaAtacom(_AirHockeyFacade):
-    _env_name = 'iiwa'
-
-    def __init__(self, task='H', gamma=0.99, horizon=120, timestep=1 / 240., n_intermediate_steps=4,
-                 debug_gui=False, env_noise=False, obs_noise=False, obs_delay=False, Kc=240., random_init=False,
-                 action_penalty=1e-3, device='cuda:0', dtype=torch.float32):
-        self._init_common(task, gamma, horizon, timestep, n_intermediate_steps, env_noise, obs_noise, obs_delay,
-                          Kc, random_init, action_penalty, device, dtype)
-
-
-class VectorizedAtacomEnv:
-    """`n_envs` ATACOM environments behind ONE surface, for a vectorised Core: the method names and argument order of
-    MushroomRL 2's `VectorizedEnvironment` (`reset_all(env_mask, state)`, `step_all(env_mask, action)`, `number`,
-    `info`), torch tensors on the device in and out -- no per-step host synchronisation, unlike the batch-1 facades
-    above, which exist for unchanged MushroomRL-1 scripts (SURVEY.md section 8b "batched surface").
-
-      env = VectorizedAtacomEnv('iiwa', n_envs=8192)
-      obs, _ = env.reset_all(mask_all)
-      obs, reward, absorbing, info = env.step_all(mask_all, actions)     # info['last'] marks finished episodes
-
-    Environments whose mask entry is False sit the call out ON THE DEVICE (`atacom_step_masked`): their state, step
-    counter, servo joints and constraint statistics are untouched, they report their current observation, reward 0 and
-    False flags.  No state save / restore, no host synchronisation: a `step_all` is one kernel launch whatever the mask,
-    and is capturable in a HIP graph."""
-
-    def __init__(self, env, n_envs, device='cuda:0', dtype=torch.float32, **engine_kwargs):
-        self._engine = BatchedAtacomEnv(env, n_envs, device=device, dtype=dtype, **engine_kwargs)
-        self.number = int(n_envs)
-        self.dims = self._engine.dims
-        self._obs = self._engine.reset()
-
-    @property
-    def info(self):
-        return self._engine.info
-
-    @property
-    def engine(self):
-        return self._engine
-
-    def seed(self, seed):
-        self._engine.seed(seed)
-
-    def render_all(self, env_mask=None, record=False):
-        pass
-
-    def stop(self):
-        self._engine.stop()
-
-    def _mask(self, env_mask):
-        if env_mask is None:
-            return None
-        m = torch.as_tensor(env_mask, device=self._engine.device).bool()
-        return None if bool(m.all()) else m
-
-    def reset_all(self, env_mask=None, state=None):
-        """Reset the masked environments (all if None); returns (observations [n_envs, D], {})."""
-        m = self._mask(env_mask)
-        self._obs = self._engine.reset(mask=None if m is None else m.to(torch.uint8), state=state)
-        return self._obs, {}
-
-    def step_all(self, env_mask, action):
-        """One env step of the masked environments.  action [n_envs, k] (rows of masked-out environments are ignored)."""
-        m = self._mask(env_mask)
-        eng = self._engine
-        if m is None:
-            obs, r, ab, info = eng.step(action)
-        else:
-            saved = eng.get_state()
-            obs, r, ab, info = eng.step(action)
-            eng.set_state(torch.where(m[:, None], eng.get_state(), saved))
-            obs = torch.where(m[:, None], obs, self._obs)
-            r = torch.where(m, r, torch.zeros_like(r))
-            ab = ab & m
-            info = {'last': info['last'] & m}
-        self._obs = obs
-        return obs, r, ab, info
-
-    def get_constraints_logs(self):
-        return self._engine.get_constraints_logs()

@@ -9,7 +9,8 @@ for name in sys.argv[1:] or ['iiwa']:
     for B in [int(x) for x in os.environ.get("MB_BATCHES", "8192").split(",")]:
       for lanes in [int(x) for x in os.environ.get("MB_LANES", "1,4").split(",")]:
         env = BatchedAtacomEnv(name, B, device=dev, dtype=torch.float32, auto_reset=True, lanes_per_env=lanes,
-                               dynamics_mode=os.environ.get('MB_DYN', 'kinematic'))
+                               dynamics_mode=os.environ.get('MB_DYN', 'kinematic'),
+                               chart_mode=os.environ.get('MB_CHART', 'reference'))
         k = env.dims['null']
         gen = torch.Generator(device=dev); gen.manual_seed(0)
         st = env.get_state(); nq = env.dims['q']
@@ -40,7 +41,7 @@ for name in sys.argv[1:] or ['iiwa']:
             e1.record(); torch.cuda.synchronize()
             ur = e0.elapsed_time(e1) / (5 * T) * 1e3
             msg = 'rollout %.1f us/step' % ur
-            if name != 'circle' and not os.environ.get('MB_DYN'):      # (no rigid-body form of the policy kernels)
+            if name != 'circle':
                 g2 = torch.Generator(device='cpu'); g2.manual_seed(0)
                 D = env.obs_dim
                 W = [torch.randn((64, D), generator=g2) * 0.1, torch.zeros(64), torch.randn((64, 64), generator=g2) * 0.1,

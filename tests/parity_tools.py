@@ -16,6 +16,23 @@ the kernel's ~10^4 rounded operations can reach); if the float64 oracle itself t
 otherwise the test FAILS.  Nothing is waved through by a percentage: a kernel bug (wrong lane, wrong row, stale
 register) produces errors where the oracle is insensitive and is caught on the first sample.
 
+SELF-AUDIT.  Where the oracle itself is that sensitive that C sens + floor exceeds REPRO_ERR, REPRO_GAIN, MAX_UNREPRODUCED = 1e-3, 5.0, 2e-3
+VACUOUS = 1e-2 the
+bound says nothing about the sample.  `finish` / `assert_matrix_fn_explained` count those samples, print the share and
+FAIL when it exceeds a per-test ceiling (default 40 %; the step tests pass what their task was calibrated to --
+reference chart: iiwa 35 % (its perturbed reset poses sit inside the rref tolerance regime: the reference itself moves
+by > 1e-2 under float32-sized perturbations on a third of them), planar 0.5 %, circle 0; canonical chart: see
+tests/test_gpu_chart.py): the rule cannot silently turn vacuous -- a kernel bug confined to ill-conditioned
+samples would need that band to grow, or is caught by the float64 build of the SAME kernels, which every step test
+runs on the same samples at 1e-8 (no sensitivity allowance there).
+
+And every LARGE error must be a branch of the reference: a sample whose error exceeds REPRO_ERR = 1e-3 is re-run through
+the float64 oracle under float32-sized perturbations of its inputs, and at least one of those evaluations must land
+REPRO_GAIN = 5 x closer to the device's result than the unperturbed oracle is (the device took the other side of a
+discontinuity the perturbations can reach).  A kernel bug is not reproduced by any perturbation of the inputs.  The few
+samples where several of a step's ~20 decisions flip at once may escape 48 draws: at most MAX_UNREPRODUCED = 0.2 % of a
+test's samples.
+
 C = 4 and floor = 5e-6 * max(1, |value|) are calibrated on 1.6e5 teacher-forced env steps per environment and kernel
 mapping (profiles/r02_parity_sensitivity.md): the largest err / sens seen was 1.7, the 99.9th percentile 0.09, the
 median below 0.01 -- the bound is a worst-case (condition-number) bound, the bulk of the errors sits at 1e-6.
@@ -27,6 +44,8 @@ import numpy as np
 QUICK_SCALES = (2e-7, 1e-6, 4e-6)
 DEEP_SCALES = (1e-6, 4e-6, 1.6e-5)
 C_SENS = 4.0
+REPRO_ERR, REPRO_GAIN, MAX_UNREPRODUCED = 1e-3, 5.0, 2e-3
+VACUOUS = 1e-2               # a bound above this says nothing: such samples are counted and capped (module docstring)
 JC_NOISE_FRACTION = 0.25     # J_c entries are perturbed at a quarter of the input scales: 5e-8 ... 1e-6 (1 to 16 float32 ulps)
 FLOOR = 5e-6
 
@@ -70,7 +89,7 @@ class SensitivityRecorder:
         self.step_fn = step_fn
         self.rng = np.random.default_rng(seed)
         self.fields = state_fields
-        self.snaps, self.inputs, self.base, self.err, self.sens, self.where = [], [], [], [], [], []
+        self.snaps, self.inputs, self.base, self.err, self.sens, self.where, self.dev = [], [], [], [], [], [], []
 
     def _sens(self, o, inputs, base, scales, draws):
         s = np.zeros(o.B)
@@ -100,7 +119,9 @@ class SensitivityRecorder:
         while len(self.err) <= t:
             self.err.append(None)
             self.where.append(None)
+            self.dev.append(None)
         self.err[t], self.where[t] = e, rel.argmax(1)
+        self.dev[t] = np.asarray(dev_out, dtype=np.float64)
         return e
 
     def record(self, o, inputs, dev_out):
@@ -112,11 +133,33 @@ class SensitivityRecorder:
     def fresh(self):
         """A recorder sharing the prepared oracle data, with an empty error log (one per device configuration)."""
         r = copy.copy(self)
-        r.err, r.where = [], []
+        r.err, r.where, r.dev = [], [], []
         r.sens = [x.copy() for x in self.sens]
         return r
 
-    def finish(self, what=''):
+    def _unreproduced(self, E):
+        """samples with E > REPRO_ERR that no perturbed oracle evaluation brings REPRO_GAIN x closer to the device"""
+        big = np.argwhere(E > REPRO_ERR)
+        out = []
+        for t in np.unique(big[:, 0]) if len(big) else []:
+            idx = big[big[:, 0] == t, 1]
+            sub = slice_env(self.snaps[t], idx)
+            sin = tuple(x[idx] for x in self.inputs[t])
+            dev = self.dev[t][idx]
+            scale = np.maximum(1.0, np.abs(dev))
+            best = np.full(len(idx), np.inf)
+            for sc in DEEP_SCALES:
+                for _ in range(16):
+                    p = perturbed(sub, sc, self.rng, self.fields)
+                    pin = tuple(x * (1.0 + sc * self.rng.choice([-1.0, 1.0], x.shape)) for x in sin)
+                    o = self.step_fn(p, pin)
+                    best = np.minimum(best, (np.abs(o - dev) / scale).max(1))
+            for j, b in enumerate(idx):
+                if best[j] > E[t, b] / REPRO_GAIN:
+                    out.append((int(t), int(b), float(E[t, b]), float(best[j])))
+        return out, len(big)
+
+    def finish(self, what='', max_vacuous=0.4):
         E, S = np.array(self.err), np.array(self.sens)
         bad = np.argwhere(E > C_SENS * S + FLOOR)
         n_deep = len(bad)
@@ -131,15 +174,22 @@ class SensitivityRecorder:
                 if E[t, b] > C_SENS * S[t, b] + FLOOR:
                     unexplained.append((int(t), int(b), float(E[t, b]), float(S[t, b]), 'output %d' % self.where[t][b]))
         ratio = E / (C_SENS * S + FLOOR)
+        vac = float(np.mean(C_SENS * S + FLOOR > VACUOUS))
         summary = ('%s: %d samples, err median %.2e / p99.9 %.2e / max %.2e; err / (C sens + floor) max %.2f; '
-                   '%d samples needed the deep probe' % (what, E.size, np.median(E), np.quantile(E, 0.999), E.max(),
-                                                         ratio.max(), n_deep))
+                   '%d samples needed the deep probe; bound vacuous (> %.0e) on %.2f %% of the samples (ceiling %.1f %%)'
+                   % (what, E.size, np.median(E), np.quantile(E, 0.999), E.max(), ratio.max(), n_deep, VACUOUS, 100 * vac,
+                      100 * max_vacuous))
+        assert vac <= max_vacuous, 'the sensitivity bound is vacuous on too many samples: ' + summary
+        unrep, n_big = self._unreproduced(E)
+        summary += '; %d errors > %.0e, %d not reproduced by a perturbed oracle' % (n_big, REPRO_ERR, len(unrep))
+        assert len(unrep) <= MAX_UNREPRODUCED * E.size, 'large errors that are no branch of the oracle ' \
+            '(t, env, err, closest perturbed oracle): %s | %s' % (unrep[:10], summary)
         assert not unexplained, 'UNEXPLAINED float32 errors (t, env, err, sens, where): %s | %s' % (unexplained[:10], summary)
         assert np.median(E) < 2e-5 and np.quantile(E, 0.99) < 2e-3, summary      # and the bulk is at rounding level
         return summary
 
 
-def assert_matrix_fn_explained(fn, A, dev_out, what='', seed=0):
+def assert_matrix_fn_explained(fn, A, dev_out, what='', seed=0, max_vacuous=0.4):
     """The same rule for a stand-alone primitive  out = fn(A)  on a batch of matrices A [n, M, N] (e.g. the chart
     rref(null(A), tol)): every float32 device result within C x (float64 fn's response to float32-sized relative
     perturbations of A) + floor; samples failing the quick estimate get the deep probe; none may stay unexplained."""
@@ -164,7 +214,9 @@ def assert_matrix_fn_explained(fn, A, dev_out, what='', seed=0):
     if len(bad):
         S[bad] = np.maximum(S[bad], sens(bad, DEEP_SCALES, 48))
     still = bad[err[bad] > C_SENS * S[bad] + FLOOR]
-    summary = '%s: %d matrices, err median %.2e max %.2e, %d needed the deep probe' % (what, len(A), np.median(err),
-                                                                                      err.max(), len(bad))
+    vac = float(np.mean(C_SENS * S + FLOOR > VACUOUS))
+    summary = '%s: %d matrices, err median %.2e max %.2e, %d needed the deep probe, bound vacuous on %.2f %%' % (
+        what, len(A), np.median(err), err.max(), len(bad), 100 * vac)
+    assert vac <= max_vacuous, 'the sensitivity bound is vacuous on too many samples: ' + summary
     assert len(still) == 0, 'UNEXPLAINED: %s | %s' % ([(int(i), float(err[i]), float(S[i])) for i in still[:10]], summary)
     return summary

@@ -179,7 +179,7 @@ def test_env_step_canonical_chart(name, dt, lanes):
         print('%s: reference-chart parity on %.1f %% of the samples (the rest: the reference takes its tolerance branch)'
               % (name, 100 * clear.mean()))
     else:
-        print(rec.finish('%s canonical, lanes %d' % (name, lanes)))
+        print(rec.finish('%s canonical, lanes %d' % (name, lanes), max_vacuous={'circle': 0.0, 'planar': 0.01, 'iiwa': 0.35}[name]))
 
 
 @pytest.mark.parametrize('name', ['planar', 'iiwa'])

@@ -4,7 +4,7 @@ the reference and (ii) the float64 oracle on identical seeded inputs.
 Stated tolerances
   float64 build : identical algorithm in double -> 1e-8 abs on states / observations (observed ~1e-12).
   float32 build : (production) EVERY sample of every step test within  C x sens + floor, sens = the float64 oracle's own
-                  response to float32-sized perturbations of the same inputs (tests/parity_tools.py: C = 10, floor =
+                  response to float32-sized perturbations of the same inputs (tests/parity_tools.py: C = 4, floor =
                   5e-6 relative to max(1, |value|); the bulk sits at 1e-6).  No percentage of samples is exempt: the
                   reference's discontinuities (the 0.05 rref pivot tolerance, atacom.py:128; contact decisions) and
                   its 1/s slack dynamics show up in sens, a kernel bug does not.
@@ -191,7 +191,7 @@ def test_env_step_teacher_forced_against_oracle(name, dt, lanes):
     if dt == 'f64':
         assert np.max(rec.err) < 1e-8, np.max(rec.err)
     else:
-        print(rec.finish('%s lanes %d' % (name, lanes)))
+        print(rec.finish('%s lanes %d' % (name, lanes), max_vacuous={'circle': 0.0, 'planar': 0.005, 'iiwa': 0.35}[name]))
     # constraint statistics accumulated on the device == oracle's (A13)
     c_dev = env.get_constraints_logs()
     assert np.allclose(c_dev, c_or, atol=1e-8 if dt == 'f64' else 2e-3)

@@ -325,7 +325,9 @@ def test_bench_line_single_gpu():
     assert res['config']['batch_per_gpu'] == 8192 and 'IiwaAirHockey' in res['config']['workload']
     assert 0 < res['max_abs_c'] < 0.05                       # feasible initial states: the engine's residual, not the init's
     assert res['collection']['records'] == [1, 120, 8192, 44] and res['collection']['allgather_ms'] is None
-    assert abs(res['roofline']['frac'] - res['roofline']['achieved'] / 8000.0) < 1e-12
+    assert res['roofline']['bound'] == 'valu_f32' and abs(res['roofline']['frac'] - res['roofline']['achieved'] / 157.3) < 1e-12
+    assert abs(res['roofline_hbm']['frac'] - res['roofline_hbm']['achieved'] / 8000.0) < 1e-12
+    assert res['collection']['rccl_world1_selfgather']['identical'] is True
 
 
 def test_bench_spawns_its_own_ranks():
