@@ -26,12 +26,13 @@ tests/test_gpu_chart.py): the rule cannot silently turn vacuous -- a kernel bug 
 samples would need that band to grow, or is caught by the float64 build of the SAME kernels, which every step test
 runs on the same samples at 1e-8 (no sensitivity allowance there).
 
-And every LARGE error must be a branch of the reference: a sample whose error exceeds REPRO_ERR = 1e-3 is re-run through
-the float64 oracle under float32-sized perturbations of its inputs, and at least one of those evaluations must land
-REPRO_GAIN = 5 x closer to the device's result than the unperturbed oracle is (the device took the other side of a
-discontinuity the perturbations can reach).  A kernel bug is not reproduced by any perturbation of the inputs.  The few
-samples where several of a step's ~20 decisions flip at once may escape 48 draws: at most MAX_UNREPRODUCED = 0.2 % of a
-test's samples.
+And LARGE errors are capped whatever the bound says: a sample whose error exceeds REPRO_ERR = 1e-3 is re-run through the
+float64 oracle under float32-sized perturbations of its inputs; unless one of those evaluations lands REPRO_GAIN = 5 x
+closer to the device's result than the unperturbed oracle is (the device took the other side of a discontinuity the
+perturbations reach) it counts as "not reproduced", and at most MAX_UNREPRODUCED = 0.2 % of a test's samples may be.
+Calibration (round 3, 40960 teacher-forced iiwa steps per mapping): 31-37 errors above 1e-3, nearly all of them from
+the CONTINUOUS hypersensitivity of the reference's null basis (random perturbations move the oracle as far, but not to the
+same point), i.e. 0.09 % -- a kernel defect confined to the ill-conditioned samples would have to hide inside that.
 
 C = 4 and floor = 5e-6 * max(1, |value|) are calibrated on 1.6e5 teacher-forced env steps per environment and kernel
 mapping (profiles/r02_parity_sensitivity.md): the largest err / sens seen was 1.7, the 99.9th percentile 0.09, the

@@ -229,9 +229,8 @@ def test_policy_rollout_in_rigid_body_mode(golden):
         out = env.rollout_policy(pol, T, noise=eps)
         assert torch.isfinite(out['reward']).all()
         env.set_state(st); env.set_aux_state(aux)
-        obs = out['obs'][0]
         for t in range(T):
-            h = torch.relu(obs @ Wd[0].T + Wd[1])
+            h = torch.relu(out['obs'][t] @ Wd[0].T + Wd[1])             # the network on the kernel's own observation
             h = torch.relu(h @ Wd[2].T + Wd[3])
             a = h @ Wd[4].T + Wd[5] + 0.3 * eps[t]
             assert torch.allclose(a, out['action'][t], atol=2e-4), (lanes, t)
