@@ -8,14 +8,14 @@ O=gpurun_out/prof_r03
 rm -rf $O; mkdir -p $O
 # 1. kernel trace + stats of the headline bench command (default = reference chart), and of the canonical-chart headline
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- \
-    python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-secondary > $O/bench_under_rocprof.log 2>&1
+    python bench.py --steps 300 --warmup 30 --min-time 0.3 --no-cpu-baseline --no-secondary > $O/bench_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_canonical -o s -- \
-    python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-secondary --chart-mode canonical > $O/bench_canonical_under_rocprof.log 2>&1
+    python bench.py --steps 300 --warmup 30 --min-time 0.3 --no-cpu-baseline --no-secondary --chart-mode canonical > $O/bench_canonical_under_rocprof.log 2>&1
 # 2. BASELINE configs 2 and 3: kernel stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_planar -o s -- \
-    python bench.py --env planar --steps 300 --warmup 30 --no-cpu-baseline --no-secondary > $O/bench_planar_under_rocprof.log 2>&1
+    python bench.py --env planar --steps 300 --warmup 30 --min-time 0.3 --no-cpu-baseline --no-secondary > $O/bench_planar_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_circle -o s -- \
-    python bench.py --env circle --batch 4096 --steps 300 --warmup 30 --no-cpu-baseline --no-secondary > $O/bench_circle_under_rocprof.log 2>&1
+    python bench.py --env circle --batch 4096 --steps 300 --warmup 30 --min-time 0.3 --no-cpu-baseline --no-secondary > $O/bench_circle_under_rocprof.log 2>&1
 # 3. HBM traffic of the step kernel, separate FETCH / WRITE passes, per workload
 for W in "0 8192 iiwa reference" "0 8192 iiwa canonical" "0 8192 planar reference" "0 4096 circle reference"; do
   T=$(echo $W | tr ' ' '_')
@@ -37,5 +37,8 @@ MB_DYN=rigid_body_ff MB_LANES=4 MB_BATCHES=8192 python tests/gpu_microbench.py i
 # 6. the bench lines: default, the driver's command
 python bench.py 2>/dev/null | tail -1 > $O/bench_default.json
 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_driver_cmd.json
+# keep the summaries, drop the per-launch traces (the merge back to the build container is capped at 64 MiB)
+find $O -name '*kernel_trace.csv' -size +2M -delete; find $O -name '*.db' -delete; find $O -name '*agent_info*' -delete
+du -sh $O
 ls -R $O | head -60
 cut -c1-600 $O/bench_driver_cmd.json

@@ -19,6 +19,7 @@
 #pragma once
 #include "atacom_envs.h"
 #include "atacom_linalg.h"
+#include "atacom_quad.h"
 
 namespace atacom {
 
@@ -99,6 +100,7 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
     const T tol2 = tol * tol;
     // ---- metric of the soft rows
     bool soft[NG], isp[NG];
+    bool has_stiff = false;
     T VT[N1][N1];                       // VT[k][i]: component k of v_i (i < NQ: joint i; i = NQ: the coordinate slack)
     T x[N1];
     {
@@ -129,6 +131,7 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
                     if (!E::jac_zero(r, j)) M(i, j) = num<T>::fma(wa[i], A[r][j], M(i, j));
             }
         }
+        has_stiff = has_p;
         T Li[NQ][NQ];
         chol_inverse_factor<T, NQ>(M, Li);
         // Gamma = Li^T Li: v_i = column i of Li (zeros above the diagonal);  x = -Gamma b = -Li^T (Li b)
@@ -204,12 +207,16 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
         for (int i = 0; i < N1; ++i) x[i] = num<T>::fma(g[i], ce, x[i]);
     };
     if constexpr (NF == 1) condition(std::integral_constant<int, 0>{}, T(0), T(0), y[0], true);
-    static_for<0, NG>([&](auto gc) {
-        constexpr int g = decltype(gc)::value;
-        if (__builtin_amdgcn_ballot_w64(!soft[g]) != 0ull)                  // wave-uniform: stiff rows are rare
-            condition(std::integral_constant<int, NF + g>{}, isp[g] ? s[g] : T(0), isp[g] ? T(0) : s[g] * s[g], y[NF + g],
-                      !soft[g]);
-    });
+    // wave-uniform and unlikely: the hot path falls through (a taken branch into cold code costs an instruction-cache
+    // miss per launch -- measured: 19 us of the first canonical k_step were such misses, profiles/r03_pmc_summary.md)
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(has_stiff) != 0ull, 0)) {
+        static_for<0, NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if (__builtin_amdgcn_ballot_w64(!soft[g]) != 0ull)
+                condition(std::integral_constant<int, NF + g>{}, isp[g] ? s[g] : T(0), isp[g] ? T(0) : s[g] * s[g],
+                          y[NF + g], !soft[g]);
+        });
+    }
     // ---- the chart: conditioning recursion over the joints with the skip rule
     T U[N1];
 #pragma unroll
@@ -235,20 +242,19 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
     // ---- free coordinates still missing after the joints: slack columns, in column order, the first one that passes.
     // The functional of slack column g on the extended state: f_g(x) = A_g u (then w_g = -f_g / s_g and
     // ||P_S e_col||^2 = |vector of f_g|^2 / s_g^2), except for the coordinate slack p: f_p(x) = w_p itself.
-    bool sel[NG], tiny[NG];
+    // (flags are recomputed where they are cheap: every bool array costs 2 SGPRs per row, and the masks spill)
+    bool sel[NG];
     T wtgt[NG];
+    auto tiny = [&](int g) -> bool { return !isp[g] && (num<T>::abs(s[g]) < CC::TINY * arow[g]); };
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        sel[g] = false; wtgt[g] = T(0);
-        tiny[g] = !isp[g] && (num<T>::abs(s[g]) < CC::TINY * arow[g]);
-    }
+    for (int g = 0; g < NG; ++g) { sel[g] = false; wtgt[g] = T(0); }
     bool done = false;
     // (A) more than one missing (0.1 % of the iiwa sub-steps): the general step, any rank
     if constexpr (NK >= 2) {
 #pragma unroll 1
         for (int it = 0; it < NK - 1; ++it) {
             const bool want = (n_acc < NK - 1) && !done;
-            if (__builtin_amdgcn_ballot_w64(want) == 0ull) break;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(want) == 0ull, 1)) break;
             T tv = alpha[0];
 #pragma unroll
             for (int i = 1; i < NK; ++i) tv = (n_acc == i) ? alpha[i] : tv;
@@ -274,7 +280,7 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
                     if (!E::jac_zero(r, i)) fu = num<T>::fma(A[r][i], U[i], fu);
                 fu = isp[g] ? U[NQ] : fu;
                 const T thr = tol2 * (isp[g] ? T(1) : s[g] * s[g]);
-                const bool pass = want && !sel[g] && (tiny[g] || (v > thr));
+                const bool pass = want && !sel[g] && (tiny(g) || (v > thr));
                 const bool take = pass && !any;
                 any = any || pass;
 #pragma unroll
@@ -282,7 +288,7 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
                 vsel = take ? v : vsel;
                 // slack g: f_g(x) = -s_g target;  coordinate slack p: f_p(x) = +target
                 rsel = take ? (isp[g] ? fu - tv : num<T>::fma(s[g], tv, fu)) : rsel;
-                tnsel = take ? tiny[g] : tnsel;
+                tnsel = take ? tiny(g) : tnsel;
                 wtgt[g] = take ? tv : wtgt[g];
                 sel[g] = sel[g] || take;
             });
@@ -346,7 +352,7 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
             res[g] = isp[g] ? U[NQ] - tv_last : num<T>::fma(s[g], tv_last, fu);
             val[g] = fd[g] * fd[g];                                 // = f_g Gamma f_g^T
             const T thr = tol2 * (isp[g] ? T(1) : s[g] * s[g]);
-            const bool pass = !sel[g] && (tiny[g] || (val[g] > thr));
+            const bool pass = !sel[g] && (tiny(g) || (val[g] > thr));
             pick[g] = need1 && pass && !any;
             any = any || pass;
             vbest = sel[g] ? vbest : num<T>::max(vbest, val[g]);
@@ -362,7 +368,7 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
         T fds = T(0), rs = T(0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            fds = pick[g] ? (tiny[g] ? T(0) : fd[g]) : fds; rs = pick[g] ? res[g] : rs;
+            fds = pick[g] ? (tiny(g) ? T(0) : fd[g]) : fds; rs = pick[g] ? res[g] : rs;
             wtgt[g] = pick[g] ? tv_last : wtgt[g];
             sel[g] = sel[g] || pick[g];
         }
@@ -406,6 +412,380 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
         // a free slack coordinate takes its target itself; the coordinate slack is a component of the state
         const T w = sel[g] ? num<T>::fma(-wm, inv_s, wtgt[g]) : -(wm + wa) * inv_s;
         mu[NQ + g] = isp[g] ? x[NQ] + U[NQ] : w;
+    }
+}
+
+
+// ------------------------------------------------------------------ the same recursion, LG lanes per environment
+// The vectors are DISTRIBUTED over the lanes of the group: v_i lives in lane i % LG, slot i / LG (S = ceil(N1 / LG) slots;
+// 8 lanes: one vector per lane for the iiwa task), together with "its" coordinates x_i, U_i.  A projection step is then
+// local work on the own vector(s): g_i = v_i . w and v_i -= c g_i w -- 2 N1 multiply-adds per slot instead of 2 N1^2 --
+// once w is known to every lane: a broadcast from the owner when w is one of the vectors (the joint steps), a group sum
+// of the lanes' contributions when it is a combination (a constraint row).  The small dense prologue (metric, Cholesky
+// factor) and the final assembly are replicated, like everything else outside the solver in the group kernels; every
+// decision is taken on replicated or group-summed values, so the lanes of a group agree bit for bit.
+// Cross-lane traffic: DPP broadcasts / butterfly sums (atacom_quad.h) and, once per slack stage, one ds_bpermute gather of
+// the longest vector (its owner is data dependent).
+template <typename T>
+__device__ __forceinline__ T lane_gather(T v, int src_lane) {
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
+    } else {
+        const long long b = __builtin_bit_cast(long long, v);
+        const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b & 0xffffffffll));
+        const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
+        return __builtin_bit_cast(T, ((long long)hi << 32) | (unsigned int)lo);
+    }
+}
+
+template <typename T, typename E, int LG>
+__device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], const T (&arow)[E::NG], const T (&s)[E::NG],
+                                                   const T (&y)[E::NC], const T (&alpha)[E::NK], const T tol, T (&mu)[E::NN],
+                                                   const int lq) {
+    constexpr int NQ = E::NQ, NF = E::NF, NG = E::NG, NK = NQ - NF, N1 = NQ + 1;
+    constexpr int S = (N1 + LG - 1) / LG;
+    static_assert(NF <= 1, "at most one equality row");
+    using CC = chart_const<T>;
+    const T tol2 = tol * tol;
+    T oh[LG];                                     // one-hot of the lane's position in its group (blend, never a switch)
+#pragma unroll
+    for (int l = 0; l < LG; ++l) oh[l] = (lq == l) ? T(1) : T(0);
+    // element (LG sl + lq) of a replicated, compile-time indexed family z(i), i < N1 (0 past the end)
+    auto own = [&](auto&& z, int sl) -> T {
+        T v = T(0);
+#pragma unroll
+        for (int l = 0; l < LG; ++l)
+            if (LG * sl + l < N1) v = num<T>::fma(oh[l], z(LG * sl + l), v);
+        return v;
+    };
+    // ---- replicated prologue: metric of the soft rows, its Cholesky factor
+    bool soft[NG], isp[NG];
+    bool has_stiff = false;
+    T VL[S][N1], xl[S], Ul[S];
+    {
+        SymMat<T, NQ> M;
+        T b[NQ];
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            b[i] = T(0);
+#pragma unroll
+            for (int j = 0; j <= i; ++j) M(i, j) = (i == j) ? T(1) : T(0);
+        }
+        bool has_p = false;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int r = NF + g;
+            soft[g] = num<T>::abs(s[g]) >= CC::THETA * arow[g];
+            isp[g] = !soft[g] && !has_p;
+            has_p = has_p || !soft[g];
+            const T om = soft[g] ? num<T>::rcp(s[g] * s[g]) : T(0);
+            T wa[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                if (E::jac_zero(r, i)) continue;
+                wa[i] = om * A[r][i];
+                b[i] = num<T>::fma(wa[i], y[r], b[i]);
+#pragma unroll
+                for (int j = 0; j <= i; ++j)
+                    if (!E::jac_zero(r, j)) M(i, j) = num<T>::fma(wa[i], A[r][j], M(i, j));
+            }
+        }
+        has_stiff = has_p;
+        T Li[NQ][NQ];
+        chol_inverse_factor<T, NQ>(M, Li);
+        T z[NQ], x0[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            T a = T(0);
+#pragma unroll
+            for (int j = 0; j <= k; ++j) a = num<T>::fma(Li[k][j], b[j], a);
+            z[k] = a;
+        }
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            T a = T(0);
+#pragma unroll
+            for (int k = i; k < NQ; ++k) a = num<T>::fma(Li[k][i], z[k], a);
+            x0[i] = -a;
+        }
+        const T hp = has_p ? T(1) : T(0);
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl) {
+            xl[sl] = own([&](int i) { return i < NQ ? x0[i < NQ ? i : 0] : T(0); }, sl);
+            Ul[sl] = T(0);
+#pragma unroll
+            for (int k = 0; k < N1; ++k)
+                VL[sl][k] = own([&](int i) {
+                    return (k < NQ && i < NQ) ? ((k >= i) ? Li[k < NQ ? k : 0][i < NQ ? i : 0] : T(0))
+                                              : ((k == NQ && i == NQ) ? hp : T(0));
+                }, sl);
+        }
+    }
+    // g_own = v_own . w;  v_own -= cproj g_own w
+    auto project = [&](const T (&w)[N1], const T cproj, T (&g)[S]) {
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl) {
+            T a = T(0);
+#pragma unroll
+            for (int k = 0; k < N1; ++k) a = num<T>::fma(VL[sl][k], w[k], a);
+            g[sl] = a;
+            const T gc = a * cproj;
+#pragma unroll
+            for (int k = 0; k < N1; ++k) VL[sl][k] = num<T>::fma(-gc, w[k], VL[sl][k]);
+        }
+    };
+    // the vector of the functional (A_r, cw) and its value on a distributed coordinate vector: group sums
+    auto functional = [&](auto rc, const T cw, T (&w)[N1], const T (&vl)[S], T& fval) {
+        constexpr int r = decltype(rc)::value;
+        T part = T(0);
+#pragma unroll
+        for (int k = 0; k < N1; ++k) w[k] = T(0);
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl) {
+            const T c = own([&](int i) { return i < NQ ? (E::jac_zero(r, i < NQ ? i : 0) ? T(0) : A[r][i < NQ ? i : 0]) : cw; }, sl);
+#pragma unroll
+            for (int k = 0; k < N1; ++k) w[k] = num<T>::fma(c, VL[sl][k], w[k]);
+            part = num<T>::fma(c, vl[sl], part);
+        }
+#pragma unroll
+        for (int k = 0; k < N1; ++k) w[k] = qsum<LG>(w[k]);
+        fval = qsum<LG>(part);
+    };
+    auto condition = [&](auto rc, const T cw, const T s2, const T yr, const bool on) {
+        constexpr int r = decltype(rc)::value;
+        T w[N1], g[S], fx;
+        functional(rc, cw, w, xl, fx);
+        T ww = T(0), nrm = num<T>::fma(cw, cw, s2);
+#pragma unroll
+        for (int k = 0; k < N1; ++k) ww = num<T>::fma(w[k], w[k], ww);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+            if (!E::jac_zero(r, i)) nrm = num<T>::fma(A[r][i], A[r][i], nrm);
+        const T e = -yr - fx;
+        const T Sv = s2 + ww;
+        const bool ok = on && (Sv > CC::REL * nrm);
+        const T iS = ok ? num<T>::rcp(Sv) : T(0);
+        const T c = iS * num<T>::rcp(T(1) + num<T>::sqrt(s2 * iS));
+        project(w, c, g);
+        const T ce = e * iS;
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl) xl[sl] = num<T>::fma(g[sl], ce, xl[sl]);
+    };
+    if constexpr (NF == 1) condition(std::integral_constant<int, 0>{}, T(0), T(0), y[0], true);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(has_stiff) != 0ull, 0)) {
+        static_for<0, NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if (__builtin_amdgcn_ballot_w64(!soft[g]) != 0ull)
+                condition(std::integral_constant<int, NF + g>{}, isp[g] ? s[g] : T(0), isp[g] ? T(0) : s[g] * s[g],
+                          y[NF + g], !soft[g]);
+        });
+    }
+    // ---- the chart: conditioning recursion over the joints with the skip rule
+    int n_acc = 0;
+    static_for<0, NQ>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        T w[N1], g[S];
+        T dj = T(0);
+#pragma unroll
+        for (int k = 0; k < N1; ++k) { w[k] = qbcast<j % LG, LG>(VL[j / LG][k]); dj = num<T>::fma(w[k], w[k], dj); }
+        const bool acc = (n_acc < NK) && (dj > tol2);
+        T tv = alpha[0];
+#pragma unroll
+        for (int i = 1; i < NK; ++i) tv = (n_acc == i) ? alpha[i] : tv;
+        const T inv = acc ? num<T>::rcp(dj) : T(0);
+        const T coef = (tv - qbcast<j % LG, LG>(Ul[j / LG])) * inv;
+        project(w, inv, g);
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl) Ul[sl] = num<T>::fma(g[sl], coef, Ul[sl]);
+        n_acc += acc ? 1 : 0;
+    });
+    // ---- free coordinates still missing after the joints (see canonical_mu)
+    // (flags are recomputed where they are cheap: every bool array costs 2 SGPRs per row, and the masks spill)
+    bool sel[NG];
+    T wtgt[NG];
+    auto tiny = [&](int g) -> bool { return !isp[g] && (num<T>::abs(s[g]) < CC::TINY * arow[g]); };
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { sel[g] = false; wtgt[g] = T(0); }
+    bool done = false;
+    if constexpr (NK >= 2) {
+#pragma unroll 1
+        for (int it = 0; it < NK - 1; ++it) {
+            const bool want = (n_acc < NK - 1) && !done;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(want) == 0ull, 1)) break;
+            T tv = alpha[0];
+#pragma unroll
+            for (int i = 1; i < NK; ++i) tv = (n_acc == i) ? alpha[i] : tv;
+            T wsel[N1], vsel = T(0), rsel = T(0);
+#pragma unroll
+            for (int k = 0; k < N1; ++k) wsel[k] = T(0);
+            bool any = false, tnsel = false;
+            static_for<0, NG>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                T wa[N1], wp[N1], fa, fp, v = T(0);
+                functional(std::integral_constant<int, NF + g>{}, T(0), wa, Ul, fa);           // f_g = A_g u
+                // the coordinate slack: f_p = w_p, i.e. the vector v_NQ and the coordinate U_NQ themselves
+#pragma unroll
+                for (int k = 0; k < N1; ++k) wp[k] = qbcast<NQ % LG, LG>(VL[NQ / LG][k]);
+                fp = qbcast<NQ % LG, LG>(Ul[NQ / LG]);
+                T wg[N1];
+#pragma unroll
+                for (int k = 0; k < N1; ++k) { wg[k] = isp[g] ? wp[k] : wa[k]; v = num<T>::fma(wg[k], wg[k], v); }
+                const T fu = isp[g] ? fp : fa;
+                const T thr = tol2 * (isp[g] ? T(1) : s[g] * s[g]);
+                const bool pass = want && !sel[g] && (tiny(g) || (v > thr));
+                const bool take = pass && !any;
+                any = any || pass;
+#pragma unroll
+                for (int k = 0; k < N1; ++k) wsel[k] = take ? wg[k] : wsel[k];
+                vsel = take ? v : vsel;
+                rsel = take ? (isp[g] ? fu - tv : num<T>::fma(s[g], tv, fu)) : rsel;
+                tnsel = take ? tiny(g) : tnsel;
+                wtgt[g] = take ? tv : wtgt[g];
+                sel[g] = sel[g] || take;
+            });
+            done = done || (want && !any);
+            const bool live = any && (vsel > T(0)) && !tnsel;
+            const T iv = live ? num<T>::rcp(vsel) : T(0);
+            T g[S];
+            project(wsel, iv, g);
+            const T coef = rsel * iv;
+#pragma unroll
+            for (int sl = 0; sl < S; ++sl) Ul[sl] = num<T>::fma(-g[sl], coef, Ul[sl]);
+            n_acc += any ? 1 : 0;
+        }
+    }
+    // (B) exactly one missing: every v_i = beta_i dhat
+    const bool need1 = (n_acc == NK - 1) && !done;
+    const T tv_last = alpha[NK - 1];
+    // the coordinates, replicated (needed by stage B and by the assembly)
+    T xa[N1], Ua[N1];
+    auto gather_all = [&]() {
+        static_for<0, N1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            xa[i] = qbcast<i % LG, LG>(xl[i / LG]);
+            Ua[i] = qbcast<i % LG, LG>(Ul[i / LG]);
+        });
+    };
+    if (__builtin_amdgcn_ballot_w64(need1) != 0ull) {
+        // the longest vector (first maximum in coordinate order, like np.argmax) and who owns it
+        T nrm2[N1];
+        static_for<0, N1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            T a = T(0);
+#pragma unroll
+            for (int k = 0; k < N1; ++k) a = num<T>::fma(VL[i / LG][k], VL[i / LG][k], a);
+            nrm2[i] = qbcast<i % LG, LG>(a);
+        });
+        T sig = nrm2[0];
+        int jm = 0;
+#pragma unroll
+        for (int j = 1; j < N1; ++j) {
+            const bool better = nrm2[j] > sig;
+            sig = better ? nrm2[j] : sig;
+            jm = better ? j : jm;
+        }
+        const int lane = (int)(threadIdx.x & 63u);
+        const int src = lane - lq + (jm % LG);
+        const int jsl = jm / LG;
+        T dh[N1];
+#pragma unroll
+        for (int k = 0; k < N1; ++k) {
+            T v = VL[0][k];
+#pragma unroll
+            for (int sl = 1; sl < S; ++sl) v = (jsl == sl) ? VL[sl][k] : v;
+            dh[k] = lane_gather(v, src);
+        }
+        const T isd = (sig > T(0)) ? num<T>::rcp(num<T>::sqrt(sig)) : T(0);
+        T bl[S];
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl) {
+            T a = T(0);
+#pragma unroll
+            for (int k = 0; k < N1; ++k) a = num<T>::fma(VL[sl][k], dh[k] * isd, a);
+            bl[sl] = a;
+        }
+        T beta[N1];
+        static_for<0, N1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            beta[i] = qbcast<i % LG, LG>(bl[i / LG]);
+            Ua[i] = qbcast<i % LG, LG>(Ul[i / LG]);
+        });
+        T fd[NG], res[NG], val[NG];
+        bool pick[NG];
+        bool any = false;
+        T vbest = T(-1);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int r = NF + g;
+            T a = T(0), fu = T(0);
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                if (E::jac_zero(r, i)) continue;
+                a = num<T>::fma(A[r][i], beta[i], a);
+                fu = num<T>::fma(A[r][i], Ua[i], fu);
+            }
+            fd[g] = isp[g] ? beta[NQ] : a;
+            res[g] = isp[g] ? Ua[NQ] - tv_last : num<T>::fma(s[g], tv_last, fu);
+            val[g] = fd[g] * fd[g];
+            const T thr = tol2 * (isp[g] ? T(1) : s[g] * s[g]);
+            const bool pass = !sel[g] && (tiny(g) || (val[g] > thr));
+            pick[g] = need1 && pass && !any;
+            any = any || pass;
+            vbest = sel[g] ? vbest : num<T>::max(vbest, val[g]);
+        }
+        bool taken = false;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const bool fb = need1 && !any && !taken && !sel[g] && (val[g] == vbest);
+            pick[g] = pick[g] || fb;
+            taken = taken || fb;
+        }
+        T fds = T(0), rs = T(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            fds = pick[g] ? (tiny(g) ? T(0) : fd[g]) : fds; rs = pick[g] ? res[g] : rs;
+            wtgt[g] = pick[g] ? tv_last : wtgt[g];
+            sel[g] = sel[g] || pick[g];
+        }
+        const T coef = (need1 && fds != T(0)) ? num<T>::div(rs, fds) : T(0);
+#pragma unroll
+        for (int sl = 0; sl < S; ++sl) Ul[sl] = num<T>::fma(-bl[sl], coef, Ul[sl]);
+    }
+    gather_all();
+    // ---- assembly (replicated), as in canonical_mu
+    if constexpr (NF == 1) {
+        T aa = T(0), au = y[0], aU = T(0);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            if (E::jac_zero(0, i)) continue;
+            aa = num<T>::fma(A[0][i], A[0][i], aa);
+            au = num<T>::fma(A[0][i], xa[i], au);
+            aU = num<T>::fma(A[0][i], Ua[i], aU);
+        }
+        const T iaa = (aa > T(0)) ? num<T>::rcp(aa) : T(0);
+        au *= iaa; aU *= iaa;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            if (E::jac_zero(0, i)) continue;
+            xa[i] = num<T>::fma(-A[0][i], au, xa[i]);
+            Ua[i] = num<T>::fma(-A[0][i], aU, Ua[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) mu[i] = xa[i] + Ua[i];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int r = NF + g;
+        T wm = y[r], wa = T(0);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            if (E::jac_zero(r, i)) continue;
+            wm = num<T>::fma(A[r][i], xa[i], wm);
+            wa = num<T>::fma(A[r][i], Ua[i], wa);
+        }
+        const T inv_s = (num<T>::abs(s[g]) >= CC::TINY * arow[g]) ? num<T>::rcp(s[g]) : T(0);
+        const T w = sel[g] ? num<T>::fma(-wm, inv_s, wtgt[g]) : -(wm + wa) * inv_s;
+        mu[NQ + g] = isp[g] ? xa[NQ] + Ua[NQ] : w;
     }
 }
 

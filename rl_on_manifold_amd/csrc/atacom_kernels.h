@@ -310,8 +310,8 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
 // LANES = 1: one environment per lane (atacom_linalg.h).  LANES = 4: one environment per DPP quad -- the
 // null-space solve is column-split over the quad (atacom_quad.h), everything else is computed redundantly
 // (and bitwise identically) by the four lanes; `lq` is the lane's index in its quad.
-// CHART = 1: the opt-in canonical chart (atacom_chart.h) instead of the reference's LAPACK-basis + rref(tol) chart; every
-// lane of a group then computes the (small) solve redundantly, like everything else outside the group solver.
+// CHART = 1: the opt-in canonical chart (atacom_chart.h) instead of the reference's LAPACK-basis + rref(tol) chart; with
+// LANES > 1 its square-root recursion is distributed over the lanes of the group (one vector per lane with 8 lanes).
 template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, bool HOIST_G0 = true, int CHART = 0>
 __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st, const T (&act)[E::NK],
                                          StepOut<T>& out, const int lq) {
@@ -474,7 +474,8 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
             y[r] = (r >= NF) ? num<T>::fma(T(0.5) * P.Kc[r] * sv, sv, yb[r]) : yb[r];
         }
         if constexpr (CANON) {
-            canonical_mu<T, E>(A, arow, st.s, y, alpha, P.rref_tol, mu);
+            if constexpr (LANES == 1) canonical_mu<T, E>(A, arow, st.s, y, alpha, P.rref_tol, mu);
+            else canonical_mu_group<T, E, LANES>(A, arow, st.s, y, alpha, P.rref_tol, mu, lq);
         } else if (LANES == 1 || E::MODE != 0) {
             T x[NN], nb[NN][NN - NC], nmu[NN];
             auto aget = [&](auto rc, auto cc) -> T {

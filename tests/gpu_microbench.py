@@ -20,7 +20,7 @@ for name in sys.argv[1:] or ['iiwa']:
             init[:, 2 * nq:] = st[:, 2 * nq + env.dims['g']: 2 * nq + env.dims['g'] + 6]
             env.reset(state=init)
         a = torch.rand((16, B, k), device=dev, generator=gen) * 2 - 1
-        for i in range(10): env.step_into(a[i % 16], env._obs, env._reward, env._absorbing, env._last)
+        for i in range(int(os.environ.get('MB_WARM', '10'))): env.step_into(a[i % 16], env._obs, env._reward, env._absorbing, env._last)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 100
