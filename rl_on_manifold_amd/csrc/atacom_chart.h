@@ -229,9 +229,12 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
 #pragma unroll
         for (int k = 0; k < N1; ++k) { w[k] = VT[k][j]; dj = num<T>::fma(w[k], w[k], dj); }
         const bool acc = (n_acc < NK) && (dj > tol2);
-        T tv = alpha[0];
+        // alpha[n_acc] as a one-hot blend: written as a select chain the optimiser turns it into a dynamically indexed
+        // private array, promotes that to LDS, and -- to address it -- reads the workgroup size from the AQL dispatch packet
+        // in HOST memory: 2 us per wave alone, up to 13 us with a full launch queueing for it (tests/gpu_phase_probe.py)
+        T tv = T(0);
 #pragma unroll
-        for (int i = 1; i < NK; ++i) tv = (n_acc == i) ? alpha[i] : tv;
+        for (int i = 0; i < NK; ++i) tv = num<T>::fma((n_acc == i) ? T(1) : T(0), alpha[i], tv);
         const T inv = acc ? num<T>::rcp(dj) : T(0);
         const T coef = (tv - U[j]) * inv;
         project(w, inv, g);
@@ -255,9 +258,9 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
         for (int it = 0; it < NK - 1; ++it) {
             const bool want = (n_acc < NK - 1) && !done;
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(want) == 0ull, 1)) break;
-            T tv = alpha[0];
+            T tv = T(0);                            // one-hot blend, see the joint recursion
 #pragma unroll
-            for (int i = 1; i < NK; ++i) tv = (n_acc == i) ? alpha[i] : tv;
+            for (int i = 0; i < NK; ++i) tv = num<T>::fma((n_acc == i) ? T(1) : T(0), alpha[i], tv);
             T wsel[N1], vsel = T(0), rsel = T(0);
 #pragma unroll
             for (int k = 0; k < N1; ++k) wsel[k] = T(0);
@@ -589,9 +592,12 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
 #pragma unroll
         for (int k = 0; k < N1; ++k) { w[k] = qbcast<j % LG, LG>(VL[j / LG][k]); dj = num<T>::fma(w[k], w[k], dj); }
         const bool acc = (n_acc < NK) && (dj > tol2);
-        T tv = alpha[0];
+        // alpha[n_acc] as a one-hot blend: written as a select chain the optimiser turns it into a dynamically indexed
+        // private array, promotes that to LDS, and -- to address it -- reads the workgroup size from the AQL dispatch packet
+        // in HOST memory: 2 us per wave alone, up to 13 us with a full launch queueing for it (tests/gpu_phase_probe.py)
+        T tv = T(0);
 #pragma unroll
-        for (int i = 1; i < NK; ++i) tv = (n_acc == i) ? alpha[i] : tv;
+        for (int i = 0; i < NK; ++i) tv = num<T>::fma((n_acc == i) ? T(1) : T(0), alpha[i], tv);
         const T inv = acc ? num<T>::rcp(dj) : T(0);
         const T coef = (tv - qbcast<j % LG, LG>(Ul[j / LG])) * inv;
         project(w, inv, g);
@@ -612,9 +618,9 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
         for (int it = 0; it < NK - 1; ++it) {
             const bool want = (n_acc < NK - 1) && !done;
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(want) == 0ull, 1)) break;
-            T tv = alpha[0];
+            T tv = T(0);                            // one-hot blend, see the joint recursion
 #pragma unroll
-            for (int i = 1; i < NK; ++i) tv = (n_acc == i) ? alpha[i] : tv;
+            for (int i = 0; i < NK; ++i) tv = num<T>::fma((n_acc == i) ? T(1) : T(0), alpha[i], tv);
             T wsel[N1], vsel = T(0), rsel = T(0);
 #pragma unroll
             for (int k = 0; k < N1; ++k) wsel[k] = T(0);
