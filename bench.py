@@ -286,6 +286,13 @@ def main():
         sys.exit('bench.py: --gpus %d contradicts WORLD_SIZE=%d of the launcher' % (args.gpus, world))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # The contract is ONE JSON line on stdout.  Libraries write there too -- RCCL 2.26 prints a five-line version banner
+    # through C stdio at communicator creation, and being block-buffered on a pipe it comes out at process exit, AFTER the
+    # JSON line.  So: file descriptor 1 is pointed at stderr for the whole run (Python's own prints included) and the
+    # JSON line alone goes to a private duplicate of the real stdout.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     if world > 1:
         # before the HIP / HSA runtime comes up (first torch.cuda call): the host driver only supports dmabuf IPC
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -445,7 +452,9 @@ def main():
         if not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.env, args.cpu_seconds, dev, init, k)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        json_out.write(json.dumps(result) + '\n')
+        json_out.flush()
+    json_out.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

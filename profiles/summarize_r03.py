@@ -69,7 +69,7 @@ def main():
     # SQ counters
     names = ['SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES', 'SQ_ACTIVE_INST_VALU', 'SQ_WAIT_ANY',
              'SQ_WAIT_INST_ANY', 'SQ_BUSY_CYCLES']
-    ws = ['0_8192_iiwa_reference', '0_8192_iiwa_canonical', '4_8192_iiwa_canonical', '0_65536_iiwa_canonical',
+    ws = ['0_8192_iiwa_reference', '0_8192_iiwa_canonical', '1_8192_iiwa_canonical', '0_65536_iiwa_canonical',
           '0_8192_planar_reference', '0_8192_planar_canonical']
     sq = {w: agg(one('pmc_sq_%s/**/*counter_collection.csv' % w)) for w in ws}
     out += ['## SQ counters per launch of the step kernel (lanes_batch_env_chart)', '', '| counter | ' + ' | '.join(ws) + ' |',
@@ -85,8 +85,9 @@ def main():
     print('\n'.join(out))
     for n in ('bench_default', 'bench_driver_cmd'):
         shutil.copy(os.path.join(SRC, n + '.json'), os.path.join(HERE, 'r03_' + n + '.json'))
-    for n in ('lanes_vs_batch_canonical', 'lanes_vs_batch_reference', 'rigid_body'):
-        shutil.copy(os.path.join(SRC, n + '.log'), os.path.join(HERE, 'r03_' + n + '.log'))
+    for n in ('lanes_vs_batch_canonical', 'lanes_vs_batch_reference', 'rigid_body', 'phase_probe'):
+        if os.path.exists(os.path.join(SRC, n + '.log')):
+            shutil.copy(os.path.join(SRC, n + '.log'), os.path.join(HERE, 'r03_' + n + '.log'))
 
 
 if __name__ == '__main__':

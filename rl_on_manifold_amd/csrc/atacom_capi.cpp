@@ -72,15 +72,26 @@ constexpr int kStatBlocks = 256;
 // network 25.0 vs 26.5) and take it.  The state layout does not depend on the mapping, so the kernels of one handle may
 // differ.  planar (6 x 9): the quad is the widest that pays.
 // Two variants run fewer mappings: the rigid-body kernels (dynamics_mode 1) exist per lane and per quad only -- 8 -> 4,
-// 2 -> 1, and atacom_get_lanes reports what really runs; the canonical chart (chart_mode 1) does its small solve per
-// lane, so the automatic choice is one environment per lane (a wider group only repeats the work; explicit requests are
-// honoured, every mapping exists).
+// 2 -> 1, and atacom_get_lanes reports what really runs.  The canonical chart (chart_mode 1) distributes the vectors of
+// its square-root recursion over the lanes of a group (atacom_chart.h): the gain per lane added is smaller than with the
+// reference chart's 12 x 17 factorisation, so the groups narrow earlier -- iiwa single steps 4 lanes up to 16384 envs
+// (34.3 vs 36.3 us with one lane at 8192) then one lane (40 us at 32768, 2 lanes 41.6); T-step kernels 8 lanes up to
+// 8192 (21.0 us per step), 4 up to 16384 (22.6), 2 up to 32768 (25.7), one beyond (28.8 at 65536); planar single steps
+// one lane (13.8 vs 14.5 us), its T-step kernels like the reference chart's (profiles/r03_lanes_vs_batch_canonical.log).
 enum { KIND_STEP = 0, KIND_ROLLOUT = 1 };
 int pick_lanes_raw(const atacom_config& c, int kind) {
     if (c.lanes_per_env == 1 || c.lanes_per_env == 2 || c.lanes_per_env == 4 || c.lanes_per_env == 8)
         return c.lanes_per_env;
     if (c.dtype == ATACOM_F64) return 1;
-    if (c.chart_mode == 1) return 1;
+    if (c.chart_mode == 1) {
+        if (c.env_id == ATACOM_ENV_IIWA) {
+            if (kind == KIND_STEP) return c.batch <= 16384 ? 4 : 1;
+            return c.batch <= 8192 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));
+        }
+        if (c.env_id == ATACOM_ENV_PLANAR && kind == KIND_ROLLOUT)
+            return c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1);
+        return 1;
+    }
     if (c.env_id == ATACOM_ENV_IIWA) {
         const int upto8 = (kind == KIND_ROLLOUT) ? 8192 : 4096;
         return c.batch <= upto8 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));

@@ -13,15 +13,28 @@
 //   chart: Cholesky of Gamma in joint order that skips a joint whose current diagonal ||P_S e_j||^2 <= tol^2; missing
 //   free coordinates go to the first slack columns that pass; N alpha falls out of the same recursion
 //   w_g = -(y_g + A_g u) / s_g with the true slack.
-// Cost for the iiwa task (12 x 17): ~1.3 k multiply-adds per sub-step against ~4.2 k for the LAPACK-basis chart.
-// Everything is straight-line code on compile-time indices; the data-dependent parts are selects, except two wave-uniform
-// ballots (stiff rows, slack coordinate) that skip work no lane of the wavefront needs.
+// Cost for the iiwa task (12 x 17): 15.9 kFLOP per env-step against 52.2 k for the LAPACK-basis chart (bench.py:
+// algorithmic_flops_canonical); measured 8.6 k vector instructions per wave and step against 11.8 k.
+// The plain path is straight-line code on compile-time indices with selects for the data-dependent choices; the rare
+// parts sit behind wave-uniform ballots -- the stiff rows and the slack stages -- and work on PER-LANE ROWS (below).
 #pragma once
 #include "atacom_envs.h"
 #include "atacom_linalg.h"
 #include "atacom_quad.h"
 
 namespace atacom {
+
+// tuning build only (tests/gpu_phase_probe.py): how often a wavefront went through the data-dependent parts of the chart --
+// [0] trips of the stiff-row loop, [1] trips of slack stage A, [2] slack stage B
+#ifdef ATACOM_TIMESTAMPS
+#define ATACOM_DBG_PARAM , int (&dbg)[3]
+#define ATACOM_DBG_ARG(d) , d
+#define ATACOM_DBG_COUNT(i) dbg[i] += 1
+#else
+#define ATACOM_DBG_PARAM
+#define ATACOM_DBG_ARG(d)
+#define ATACOM_DBG_COUNT(i)
+#endif
 
 template <typename T> struct chart_const {
     static constexpr T THETA = T(3e-2);     // stiff-row threshold (oracle/canonical_chart.py: THETA)
@@ -74,6 +87,74 @@ __device__ __forceinline__ void chol_inverse_factor(const SymMat<T, N>& M, T (&L
     }
 }
 
+// A row of A as a conditioning step sees it: row R known at compile time (its structural zeros cost nothing) ...
+template <typename T, typename E, int R>
+struct StaticRow {
+    const T (&A)[E::NC][E::NQ];
+    static constexpr bool zero(int i) { return E::jac_zero(R, i); }
+    __device__ __forceinline__ T operator()(int i) const { return A[R][i]; }
+};
+// ... or the lane's OWN row: every lane of the wavefront conditions on a different row in the same instructions
+template <typename T, typename E>
+struct LaneRow {
+    T v[E::NQ];
+    static constexpr bool zero(int) { return false; }
+    __device__ __forceinline__ T operator()(int i) const { return v[i]; }
+};
+// Row (NF + g) of A for the g whose bit is `low` (at most one bit; none: the zero row), and entry g of a per-row family:
+// one-hot blends -- exact (1 * a + 0 * ...), and never a switch (see the note on alpha in canonical_mu).
+template <typename T, typename E>
+__device__ __forceinline__ void lane_row(const T (&A)[E::NC][E::NQ], const unsigned low, LaneRow<T, E>& row) {
+#pragma unroll
+    for (int i = 0; i < E::NQ; ++i) row.v[i] = T(0);
+#pragma unroll
+    for (int g = 0; g < E::NG; ++g) {
+        const T h = (low == (1u << g)) ? T(1) : T(0);
+#pragma unroll
+        for (int i = 0; i < E::NQ; ++i)
+            if (!E::jac_zero(E::NF + g, i)) row.v[i] = num<T>::fma(h, A[E::NF + g][i], row.v[i]);
+    }
+}
+template <typename T, int NG, typename Z>
+__device__ __forceinline__ T lane_pick(Z&& z, const unsigned low) {
+    T v = T(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) v = num<T>::fma((low == (1u << g)) ? T(1) : T(0), z(g), v);
+    return v;
+}
+// PER-LANE ROWS.  The data-dependent parts of the chart -- conditioning on the stiff rows, the scan of the slack columns
+// for a missing free coordinate -- touch ONE row per environment, a different one in each.  Written per row (static_for
+// over the rows, each under a wave-uniform ballot) a wavefront runs one step per DISTINCT row among its environments; per
+// lane (trip n: every lane works on ITS n-th row, gathered by lane_row) it is one trip, rarely two.  Measured on
+// constraint-active iiwa states (tests/gpu_phase_probe.py, path counters of the tuning build; 8192 environments, 4 lanes):
+// a trip of the per-row slack scan cost 2.6 us (all 11 columns evaluated for every lane) and the slowest wavefronts of a
+// launch -- four trips -- set its duration, 33 us against 15 us on quiet states.
+template <typename T, typename E, typename F>
+__device__ __forceinline__ int for_each_stiff_row(const T (&A)[E::NC][E::NQ], const T (&s)[E::NG], const T (&y)[E::NC],
+                                                  const bool (&soft)[E::NG], F&& cond) {
+    constexpr int NF = E::NF, NG = E::NG;
+    unsigned todo = 0u;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) todo |= soft[g] ? 0u : (1u << g);
+    bool first = true;
+    int trips = 0;
+#pragma unroll 1
+    while (__builtin_amdgcn_ballot_w64(todo != 0u) != 0ull) {
+        ++trips;
+        const bool on = todo != 0u;
+        const unsigned low = todo & (0u - todo);                    // the lane's next stiff row (0: it has none left)
+        todo ^= low;
+        LaneRow<T, E> row;
+        lane_row<T, E>(A, low, row);
+        const T sg = lane_pick<T, NG>([&](int g) { return s[g]; }, low);
+        const T yg = lane_pick<T, NG>([&](int g) { return y[NF + g]; }, low);
+        const bool prim = first && on;                              // the first stiff row: its slack is a coordinate
+        first = false;
+        cond(row, prim ? sg : T(0), prim ? T(0) : sg * sg, yg, on);
+    }
+    return trips;
+}
+
 // A (NC x NQ) = K J with the equality row (if any) first; arow[g] = max_c |A[NF + g][c]|; s: slacks; y = psi + Kc c;
 // alpha: the NK null coordinates.  mu (NN) = [joint accelerations | slack velocities].
 //
@@ -93,7 +174,7 @@ __device__ __forceinline__ void chol_inverse_factor(const SymMat<T, N>& M, T (&L
 // i.e. they are axpy-shaped and pack into v_pk_fma_f32 pairs.
 template <typename T, typename E>
 __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T (&arow)[E::NG], const T (&s)[E::NG],
-                                             const T (&y)[E::NC], const T (&alpha)[E::NK], const T tol, T (&mu)[E::NN]) {
+                                             const T (&y)[E::NC], const T (&alpha)[E::NK], const T tol, T (&mu)[E::NN] ATACOM_DBG_PARAM) {
     constexpr int NQ = E::NQ, NF = E::NF, NG = E::NG, NK = NQ - NF, N1 = NQ + 1;
     static_assert(NF <= 1, "at most one equality row");
     using CC = chart_const<T>;
@@ -175,8 +256,8 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
         }
     };
     // exact rank-one conditioning of the state on  (A_r, cw) . x + (noise of variance s2) = -yr
-    auto condition = [&](auto rc, const T cw, const T s2, const T yr, const bool on) {
-        constexpr int r = decltype(rc)::value;
+    auto condition = [&](const auto& row, const T cw, const T s2, const T yr, const bool on) {
+        using R = std::decay_t<decltype(row)>;
         T w[N1], g[N1];
         T ww = T(0), e = -yr, nrm = num<T>::fma(cw, cw, s2);
 #pragma unroll
@@ -184,15 +265,15 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
             T a = VT[k][NQ] * cw;
 #pragma unroll
             for (int i = 0; i < NQ; ++i)
-                if (!E::jac_zero(r, i)) a = num<T>::fma(VT[k][i], A[r][i], a);
+                if (!R::zero(i)) a = num<T>::fma(VT[k][i], row(i), a);
             w[k] = a;
             ww = num<T>::fma(a, a, ww);
         }
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            if (E::jac_zero(r, i)) continue;
-            e = num<T>::fma(-A[r][i], x[i], e);
-            nrm = num<T>::fma(A[r][i], A[r][i], nrm);
+            if (R::zero(i)) continue;
+            e = num<T>::fma(-row(i), x[i], e);
+            nrm = num<T>::fma(row(i), row(i), nrm);
         }
         e = num<T>::fma(-cw, x[NQ], e);
         const T S = s2 + ww;
@@ -206,16 +287,12 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
 #pragma unroll
         for (int i = 0; i < N1; ++i) x[i] = num<T>::fma(g[i], ce, x[i]);
     };
-    if constexpr (NF == 1) condition(std::integral_constant<int, 0>{}, T(0), T(0), y[0], true);
-    // wave-uniform and unlikely: the hot path falls through (a taken branch into cold code costs an instruction-cache
-    // miss per launch -- measured: 19 us of the first canonical k_step were such misses, profiles/r03_pmc_summary.md)
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(has_stiff) != 0ull, 0)) {
-        static_for<0, NG>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            if (__builtin_amdgcn_ballot_w64(!soft[g]) != 0ull)
-                condition(std::integral_constant<int, NF + g>{}, isp[g] ? s[g] : T(0), isp[g] ? T(0) : s[g] * s[g],
-                          y[NF + g], !soft[g]);
-        });
+    if constexpr (NF == 1) condition(StaticRow<T, E, 0>{A}, T(0), T(0), y[0], true);
+    if (__builtin_amdgcn_ballot_w64(has_stiff) != 0ull) {
+        [[maybe_unused]] const int trips = for_each_stiff_row<T, E>(A, s, y, soft, condition);
+#ifdef ATACOM_TIMESTAMPS
+        dbg[0] += trips;
+#endif
     }
     // ---- the chart: conditioning recursion over the joints with the skip rule
     T U[N1];
@@ -258,6 +335,7 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
         for (int it = 0; it < NK - 1; ++it) {
             const bool want = (n_acc < NK - 1) && !done;
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(want) == 0ull, 1)) break;
+            ATACOM_DBG_COUNT(1);
             T tv = T(0);                            // one-hot blend, see the joint recursion
 #pragma unroll
             for (int i = 0; i < NK; ++i) tv = num<T>::fma((n_acc == i) ? T(1) : T(0), alpha[i], tv);
@@ -265,6 +343,8 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
 #pragma unroll
             for (int k = 0; k < N1; ++k) wsel[k] = T(0);
             bool any = false, tnsel = false;
+            // (per row, not per lane as in canonical_mu_group: with 64 environments per wavefront the first-fit scan ran
+            // as many trips as its slowest lane -- measured slower, 41.8 against 36.3 us per step at 8192 environments)
             static_for<0, NG>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
                 constexpr int r = NF + g;
@@ -310,6 +390,7 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
     const bool need1 = (n_acc == NK - 1) && !done;
     const T tv_last = alpha[NK - 1];
     if (__builtin_amdgcn_ballot_w64(need1) != 0ull) {
+        ATACOM_DBG_COUNT(2);
         T nrm2[N1];
 #pragma unroll
         for (int i = 0; i < N1; ++i) nrm2[i] = T(0);
@@ -444,7 +525,7 @@ __device__ __forceinline__ T lane_gather(T v, int src_lane) {
 template <typename T, typename E, int LG>
 __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], const T (&arow)[E::NG], const T (&s)[E::NG],
                                                    const T (&y)[E::NC], const T (&alpha)[E::NK], const T tol, T (&mu)[E::NN],
-                                                   const int lq) {
+                                                   const int lq ATACOM_DBG_PARAM) {
     constexpr int NQ = E::NQ, NF = E::NF, NG = E::NG, NK = NQ - NF, N1 = NQ + 1;
     constexpr int S = (N1 + LG - 1) / LG;
     static_assert(NF <= 1, "at most one equality row");
@@ -538,14 +619,14 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
         }
     };
     // the vector of the functional (A_r, cw) and its value on a distributed coordinate vector: group sums
-    auto functional = [&](auto rc, const T cw, T (&w)[N1], const T (&vl)[S], T& fval) {
-        constexpr int r = decltype(rc)::value;
+    auto functional = [&](const auto& row, const T cw, T (&w)[N1], const T (&vl)[S], T& fval) {
+        using R = std::decay_t<decltype(row)>;
         T part = T(0);
 #pragma unroll
         for (int k = 0; k < N1; ++k) w[k] = T(0);
 #pragma unroll
         for (int sl = 0; sl < S; ++sl) {
-            const T c = own([&](int i) { return i < NQ ? (E::jac_zero(r, i < NQ ? i : 0) ? T(0) : A[r][i < NQ ? i : 0]) : cw; }, sl);
+            const T c = own([&](int i) { return i < NQ ? (R::zero(i < NQ ? i : 0) ? T(0) : row(i < NQ ? i : 0)) : cw; }, sl);
 #pragma unroll
             for (int k = 0; k < N1; ++k) w[k] = num<T>::fma(c, VL[sl][k], w[k]);
             part = num<T>::fma(c, vl[sl], part);
@@ -554,16 +635,16 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
         for (int k = 0; k < N1; ++k) w[k] = qsum<LG>(w[k]);
         fval = qsum<LG>(part);
     };
-    auto condition = [&](auto rc, const T cw, const T s2, const T yr, const bool on) {
-        constexpr int r = decltype(rc)::value;
+    auto condition = [&](const auto& row, const T cw, const T s2, const T yr, const bool on) {
+        using R = std::decay_t<decltype(row)>;
         T w[N1], g[S], fx;
-        functional(rc, cw, w, xl, fx);
+        functional(row, cw, w, xl, fx);
         T ww = T(0), nrm = num<T>::fma(cw, cw, s2);
 #pragma unroll
         for (int k = 0; k < N1; ++k) ww = num<T>::fma(w[k], w[k], ww);
 #pragma unroll
         for (int i = 0; i < NQ; ++i)
-            if (!E::jac_zero(r, i)) nrm = num<T>::fma(A[r][i], A[r][i], nrm);
+            if (!R::zero(i)) nrm = num<T>::fma(row(i), row(i), nrm);
         const T e = -yr - fx;
         const T Sv = s2 + ww;
         const bool ok = on && (Sv > CC::REL * nrm);
@@ -574,14 +655,12 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
 #pragma unroll
         for (int sl = 0; sl < S; ++sl) xl[sl] = num<T>::fma(g[sl], ce, xl[sl]);
     };
-    if constexpr (NF == 1) condition(std::integral_constant<int, 0>{}, T(0), T(0), y[0], true);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(has_stiff) != 0ull, 0)) {
-        static_for<0, NG>([&](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            if (__builtin_amdgcn_ballot_w64(!soft[g]) != 0ull)
-                condition(std::integral_constant<int, NF + g>{}, isp[g] ? s[g] : T(0), isp[g] ? T(0) : s[g] * s[g],
-                          y[NF + g], !soft[g]);
-        });
+    if constexpr (NF == 1) condition(StaticRow<T, E, 0>{A}, T(0), T(0), y[0], true);
+    if (__builtin_amdgcn_ballot_w64(has_stiff) != 0ull) {
+        [[maybe_unused]] const int trips = for_each_stiff_row<T, E>(A, s, y, soft, condition);
+#ifdef ATACOM_TIMESTAMPS
+        dbg[0] += trips;
+#endif
     }
     // ---- the chart: conditioning recursion over the joints with the skip rule
     int n_acc = 0;
@@ -618,6 +697,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
         for (int it = 0; it < NK - 1; ++it) {
             const bool want = (n_acc < NK - 1) && !done;
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(want) == 0ull, 1)) break;
+            ATACOM_DBG_COUNT(1);
             T tv = T(0);                            // one-hot blend, see the joint recursion
 #pragma unroll
             for (int i = 0; i < NK; ++i) tv = num<T>::fma((n_acc == i) ? T(1) : T(0), alpha[i], tv);
@@ -625,30 +705,51 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
 #pragma unroll
             for (int k = 0; k < N1; ++k) wsel[k] = T(0);
             bool any = false, tnsel = false;
-            static_for<0, NG>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-                T wa[N1], wp[N1], fa, fp, v = T(0);
-                functional(std::integral_constant<int, NF + g>{}, T(0), wa, Ul, fa);           // f_g = A_g u
-                // the coordinate slack: f_p = w_p, i.e. the vector v_NQ and the coordinate U_NQ themselves
+            // the coordinate slack: f_p = w_p, i.e. the vector v_NQ and the coordinate U_NQ themselves
+            T wp[N1];
 #pragma unroll
-                for (int k = 0; k < N1; ++k) wp[k] = qbcast<NQ % LG, LG>(VL[NQ / LG][k]);
-                fp = qbcast<NQ % LG, LG>(Ul[NQ / LG]);
+            for (int k = 0; k < N1; ++k) wp[k] = qbcast<NQ % LG, LG>(VL[NQ / LG][k]);
+            const T fp = qbcast<NQ % LG, LG>(Ul[NQ / LG]);
+            // first fit, per lane group: trip n tests the environment's n-th untaken column (PER-LANE ROWS above)
+            unsigned cand = 0u, pbit = 0u, gsel = 0u;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                cand |= (want && !sel[g]) ? (1u << g) : 0u;
+                pbit |= isp[g] ? (1u << g) : 0u;
+            }
+#pragma unroll 1
+            while (__builtin_amdgcn_ballot_w64((cand != 0u) && !any) != 0ull) {
+                const bool act = (cand != 0u) && !any;
+                const unsigned low = act ? (cand & (0u - cand)) : 0u;
+                cand ^= low;
+                LaneRow<T, E> row;
+                lane_row<T, E>(A, low, row);
+                const T sg = lane_pick<T, NG>([&](int g) { return s[g]; }, low);
+                const T ag = lane_pick<T, NG>([&](int g) { return arow[g]; }, low);
+                const bool ip = (low & pbit) != 0u;
+                T wa[N1], fa, v = T(0);
+                functional(row, T(0), wa, Ul, fa);                                             // f_g = A_g u
                 T wg[N1];
 #pragma unroll
-                for (int k = 0; k < N1; ++k) { wg[k] = isp[g] ? wp[k] : wa[k]; v = num<T>::fma(wg[k], wg[k], v); }
-                const T fu = isp[g] ? fp : fa;
-                const T thr = tol2 * (isp[g] ? T(1) : s[g] * s[g]);
-                const bool pass = want && !sel[g] && (tiny(g) || (v > thr));
-                const bool take = pass && !any;
-                any = any || pass;
+                for (int k = 0; k < N1; ++k) { wg[k] = ip ? wp[k] : wa[k]; v = num<T>::fma(wg[k], wg[k], v); }
+                const T fu = ip ? fp : fa;
+                const T thr = tol2 * (ip ? T(1) : sg * sg);
+                const bool tn = !ip && (num<T>::abs(sg) < CC::TINY * ag);
+                const bool take = act && (tn || (v > thr));
 #pragma unroll
                 for (int k = 0; k < N1; ++k) wsel[k] = take ? wg[k] : wsel[k];
                 vsel = take ? v : vsel;
-                rsel = take ? (isp[g] ? fu - tv : num<T>::fma(s[g], tv, fu)) : rsel;
-                tnsel = take ? tiny(g) : tnsel;
-                wtgt[g] = take ? tv : wtgt[g];
-                sel[g] = sel[g] || take;
-            });
+                rsel = take ? (ip ? fu - tv : num<T>::fma(sg, tv, fu)) : rsel;
+                tnsel = take ? tn : tnsel;
+                gsel = take ? low : gsel;
+                any = any || take;
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const bool tk = gsel == (1u << g);
+                wtgt[g] = num<T>::fma(tk ? T(1) : T(0), tv, wtgt[g]);
+                sel[g] = sel[g] || tk;
+            }
             done = done || (want && !any);
             const bool live = any && (vsel > T(0)) && !tnsel;
             const T iv = live ? num<T>::rcp(vsel) : T(0);
@@ -673,6 +774,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
         });
     };
     if (__builtin_amdgcn_ballot_w64(need1) != 0ull) {
+        ATACOM_DBG_COUNT(2);
         // the longest vector (first maximum in coordinate order, like np.argmax) and who owns it
         T nrm2[N1];
         static_for<0, N1>([&](auto ic) {

@@ -105,6 +105,9 @@ struct StepOut {
     T reward;
     bool absorbing, last;
     T log_avg, log_max, log_dq;
+#ifdef ATACOM_TIMESTAMPS
+    int dbg[3] = {0, 0, 0};        // tuning build: wave-level path counters of the canonical chart (atacom_chart.h)
+#endif
 };
 
 template <typename T, typename E>
@@ -474,8 +477,8 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
             y[r] = (r >= NF) ? num<T>::fma(T(0.5) * P.Kc[r] * sv, sv, yb[r]) : yb[r];
         }
         if constexpr (CANON) {
-            if constexpr (LANES == 1) canonical_mu<T, E>(A, arow, st.s, y, alpha, P.rref_tol, mu);
-            else canonical_mu_group<T, E, LANES>(A, arow, st.s, y, alpha, P.rref_tol, mu, lq);
+            if constexpr (LANES == 1) canonical_mu<T, E>(A, arow, st.s, y, alpha, P.rref_tol, mu ATACOM_DBG_ARG(out.dbg));
+            else canonical_mu_group<T, E, LANES>(A, arow, st.s, y, alpha, P.rref_tol, mu, lq ATACOM_DBG_ARG(out.dbg));
         } else if (LANES == 1 || E::MODE != 0) {
             T x[NN], nb[NN][NN - NC], nmu[NN];
             auto aget = [&](auto rc, auto cc) -> T {
@@ -717,6 +720,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
         asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts3) :: "memory");
         unsigned int* o = reinterpret_cast<unsigned int*>(obs + (size_t)b * E::OBS);
         o[0] = (unsigned int)ts0; o[1] = (unsigned int)ts1; o[2] = (unsigned int)ts2; o[3] = (unsigned int)ts3;
+        if constexpr (CHART == 1) { o[4] = out.dbg[0]; o[5] = out.dbg[1]; o[6] = out.dbg[2]; }
     }
 #endif
 }
@@ -1253,7 +1257,10 @@ __global__ void __launch_bounds__(WAVE) k_chart(int n, const T* __restrict__ Ain
     }
 #pragma unroll
     for (int k = 0; k < NK; ++k) alpha[k] = ain[(size_t)b * NK + k];
-    canonical_mu<T, E>(A, arow, s, y, alpha, tol, mu);
+#ifdef ATACOM_TIMESTAMPS
+    int dbg[3] = {0, 0, 0};
+#endif
+    canonical_mu<T, E>(A, arow, s, y, alpha, tol, mu ATACOM_DBG_ARG(dbg));
 #pragma unroll
     for (int c = 0; c < NN; ++c) mu_o[(size_t)b * NN + c] = mu[c];
 }

@@ -34,6 +34,7 @@ for rep in range(10):
     e0.record()
     env.step_into(a, env._obs, env._reward, env._absorbing, env._last)
     e1.record(); torch.cuda.synchronize()
+    raw = env._obs[:, :7].contiguous().view(torch.int32).cpu().numpy()
     ts = env._obs[:, :4].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     t0 = ts[:, 0].min()
     d = (ts - t0) * 0.01                                   # us since the first wave started
@@ -55,3 +56,14 @@ print('   waves %d | total us pct%s: %s | load: %s | compute: %s | start: %s' % 
     np.percentile(st0, q).round(1)))
 slow = np.argsort(-tot)[:8]
 print('   slowest waves (index: total)', [(int(i), float(tot[i].round(1))) for i in slow])
+if os.environ.get('MB_CHART') == 'canonical':
+    # wave-level path counters of the canonical chart over the sub-steps of the launch (csrc/atacom_chart.h, tuning build)
+    c = raw[::step, 4:7]
+    print('   per wave and launch: stiff-row trips %.2f, stage A trips %.2f, stage B %.2f' % tuple(c.mean(0)))
+    for name, col in (('stiff-row trips', 0), ('stage A trips', 1), ('stage B', 2)):
+        vals = np.unique(c[:, col])
+        print('   wave time by %s: ' % name + ', '.join('%d: %.1f us (%d waves)' % (v, tot[c[:, col] == v].mean(), (c[:, col] == v).sum())
+                                                      for v in vals))
+    Xm = np.concatenate([c.astype(float), np.ones((len(c), 1))], 1)
+    coef = np.linalg.lstsq(Xm, tot, rcond=None)[0]
+    print('   least squares: %.2f us per stiff-row trip, %.2f us per stage A trip, %.2f us per stage B, %.2f us base' % tuple(coef))

@@ -225,14 +225,22 @@ def test_canonical_chart_closed_loop_at_config_4():
     acts = torch.rand((T, B, 5), device=DEV, generator=gen) * 2 - 1
     stats = {}
     for mode in ('reference', 'canonical'):
-        env = BatchedAtacomEnv('iiwa', B, device=DEV, chart_mode=mode, auto_reset=True)
-        env.reset(state=init)
-        out = env.rollout(acts)
-        assert torch.isfinite(out['obs']).all() and torch.isfinite(out['reward']).all()
-        stats[mode] = env.get_constraints_logs()
-    (a0, m0, d0), (a1, m1, d1) = stats['reference'], stats['canonical']
-    print('c_avg / c_max / c_dq_max  reference chart %.5f %.5f %.2e   canonical chart %.5f %.5f %.2e' % (a0, m0, d0, a1, m1, d1))
-    # c_max is the largest of 1e6 env-steps on trajectories that part ways where the charts differ: a heavy-tailed
-    # statistic, compared at the 1.5x the other free-running tests use; the mean is the stable number
-    assert a1 <= 1.05 * a0 and m1 <= 1.5 * m0, stats
+        for lanes in (1, 2, 4, 8):
+            env = BatchedAtacomEnv('iiwa', B, device=DEV, chart_mode=mode, auto_reset=True, lanes_per_env=lanes)
+            env.reset(state=init)
+            out = env.rollout(acts)
+            assert torch.isfinite(out['obs']).all() and torch.isfinite(out['reward']).all()
+            stats[mode, lanes] = env.get_constraints_logs()
+    col = lambda mode, i: np.array([stats[mode, l][i] for l in (1, 2, 4, 8)])
+    for mode in ('reference', 'canonical'):
+        print('%-9s chart, 1 / 2 / 4 / 8 lanes: c_avg %s  c_max %s  c_dq_max %s' % (mode, col(mode, 0).round(5), col(mode, 1).round(4),
+                                                                                 col(mode, 2)))
+    # c_max is the largest of 1e6 env-steps on float32 trajectories that part ways at the first rounding difference: a
+    # heavy-tailed statistic -- the REFERENCE chart's own four kernel mappings spread over 0.010 ... 0.033 on these states
+    # (profiles/r03_chart_closed_loop.log) -- so the charts are compared by the median over the mappings (at the 1.5x the
+    # other free-running tests use) and every run against the absolute bound; the mean is the stable number
+    a0, a1 = col('reference', 0), col('canonical', 0)
+    assert (a1 <= 1.05 * a0.max()).all(), stats
+    assert np.median(col('canonical', 1)) <= 1.5 * np.median(col('reference', 1)), stats
+    m1, d1 = col('canonical', 1).max(), col('canonical', 2).max()
     assert d1 <= 1e-4 and m1 < 0.05

@@ -315,8 +315,11 @@ def _run_bench(extra, env=None):
                         '--min-time', '0.1', '--no-cpu-baseline', '--no-secondary'] + extra,
                        capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
-    return json.loads(line)
+    # the contract: stdout is ONE line, the JSON (RCCL's version banner, printed through C stdio at process exit, used to
+    # land behind it)
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
 
 
 def test_bench_line_single_gpu():

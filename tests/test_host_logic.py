@@ -69,8 +69,11 @@ def test_bench_helpers():
     assert 1 <= bench.usable_cores() <= (os.cpu_count() or 1)
     for name, (M, N, K, nq, sub) in bench.SHAPES.items():
         assert N - M == K and bench.ALGO_BYTES[name] > 0
-    r, rv = bench.roofline_objects('iiwa', 8192, 0.028)
+    rv, r = bench.roofline_objects('iiwa', 8192, 0.028)              # the binding roof (vector ALU) first, then the HBM view
+    assert r['bound'] == 'hbm' and rv['bound'] == 'valu_f32'
     assert abs(r['achieved'] - 400 * 8192 / 0.028e-3 / 1e9) < 1e-6 and abs(r['frac'] - r['achieved'] / 8000.0) < 1e-12
     assert rv['unit'] == 'TFLOP/s' and 0.05 < rv['frac'] < 0.2
+    rc, _ = bench.roofline_objects('iiwa', 8192, 0.028, chart='canonical')
+    assert rc['algorithmic_flops_per_launch'] < rv['algorithmic_flops_per_launch'] / 3
     port = bench._free_port()
     assert 1024 < port < 65536
