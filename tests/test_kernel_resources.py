@@ -1,0 +1,73 @@
+"""What the built library's kernels occupy, read from the code objects inside libatacom_hip.so (no GPU needed).
+
+DESIGN.md section 6 rests on "matrices live in registers: no scratch, no LDS" for the float32 production kernels.  Both
+have been lost to the optimiser without a functional symptom: a select chain rewritten into a dynamically indexed private
+array went to SCRATCH in round 1 (planar 31 -> 17 us once gone) and was PROMOTED TO LDS in round 3, where addressing it
+made every wave read the dispatch packet in host memory (2 - 26 us per launch).  This test pins the property."""
+import os
+import re
+import struct
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = '/opt/rocm/lib/llvm/bin'
+MAGIC = b'__CLANG_OFFLOAD_BUNDLE__'
+
+
+def _kernels(tmp):
+    """[(demangled name, LDS bytes, scratch bytes per lane, VGPRs)] of every gfx950 kernel in the library."""
+    from rl_on_manifold_amd import build
+    so = build.build(verbose=False)
+    fat = os.path.join(tmp, 'fat.bin')
+    subprocess.check_call([os.path.join(LLVM, 'llvm-objcopy'), '--dump-section', '.hip_fatbin=' + fat, so,
+                           os.path.join(tmp, 'copy.so')])
+    data = open(fat, 'rb').read()
+    rows = []
+    for m in re.finditer(MAGIC, data):                       # one bundle per translation unit
+        p = m.start()
+        n_entries = struct.unpack_from('<Q', data, p + 24)[0]
+        off = p + 32
+        for _ in range(n_entries):
+            o, size, id_len = struct.unpack_from('<QQQ', data, off)
+            ident = data[off + 24:off + 24 + id_len].decode()
+            off += 24 + id_len
+            if 'gfx950' not in ident or size == 0:
+                continue
+            elf = os.path.join(tmp, 'dev%d.elf' % p)
+            open(elf, 'wb').write(data[p + o:p + o + size])
+            notes = subprocess.run([os.path.join(LLVM, 'llvm-readelf'), '--notes', elf], capture_output=True, text=True,
+                                   check=True).stdout
+            for blk in notes.split('  - .agpr_count:')[1:]:
+                g = lambda k: re.search(r'\.' + k + r':\s+(\S+)', blk).group(1)      # noqa: E731
+                rows.append((g('name'), int(g('group_segment_fixed_size')), int(g('private_segment_fixed_size')),
+                             int(g('vgpr_count'))))
+    names = subprocess.run(['c++filt'] + [r[0] for r in rows], capture_output=True, text=True).stdout.strip().split('\n')
+    short = [re.sub(r'\(.*', '', n).replace('atacom::', '').replace('void ', '') for n in names]
+    return [(s,) + r[1:] for s, r in zip(short, rows)]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, 'llvm-readelf')), reason='needs the ROCm LLVM binutils')
+def test_no_promoted_arrays_and_no_scratch_in_the_production_kernels(tmp_path):
+    ks = _kernels(str(tmp_path))
+    assert len(ks) > 400                                     # 3 tasks + 2 circle baselines, 2 dtypes, 4 mappings, 2 charts, ...
+    assert any(k[0].startswith('k_step<float, Iiwa, 4, true, false, 0>') for k in ks), [k[0] for k in ks][:5]
+    # static LDS: only the two-stage statistics reduction declares any (the policy kernels' LDS is dynamic)
+    lds = [k for k in ks if k[1] != 0]
+    assert lds and all(k[0].startswith('k_stats<') for k in lds), lds
+    # float32, kinematic mode (DYN = false), every task, mapping and chart: the single-step kernels never touch scratch,
+    # and neither do the T-step kernels of the lane-group mappings
+    def args(name):
+        return [a.strip() for a in name[name.index('<') + 1:name.rindex('>')].split(',')]
+    bad = []
+    for name, _, scratch, _ in ks:
+        if not name.startswith(('k_step<float', 'k_rollout<float')):
+            continue
+        a = args(name)                                       # T, E, LANES, HOLD, DYN, CHART
+        if a[4] == 'true':
+            continue                                         # rigid-body mode: scratch allowed (opt-in)
+        if name.startswith('k_step<') or int(a[2]) > 1:
+            if scratch:
+                bad.append((name, scratch))
+    assert not bad, bad
