@@ -1,6 +1,8 @@
 """Calibration run behind tests/parity_tools.py (not a test): teacher-forced float32 env steps against the float64 oracle,
 with the oracle's own sensitivity to float32-sized perturbations (inputs + unstructured J_c noise) and its decision
-margins.  Output is pasted into profiles/r02_parity_sensitivity.md.   python tests/gpu_sens_probe.py [lanes] [B] [T]"""
+margins.  Output is pasted into profiles/r02_parity_sensitivity.md.   python tests/gpu_sens_probe.py [lanes] [B] [T]
+(MB_CHART=canonical: the opt-in chart, kernel and oracle both -- profiles/r03_sens_soak_canonical_l*.log)"""
+import dataclasses
 import os
 import sys
 import numpy as np
@@ -16,8 +18,10 @@ from parity_tools import SensitivityRecorder, C_SENS, FLOOR
 lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+CHART = os.environ.get('MB_CHART', 'reference')
 for name, spec in (('circle', osc.circle_spec()), ('planar', osc.planar_spec()), ('iiwa', osc.iiwa_spec())):
-    env = BatchedAtacomEnv(name, B, device='cuda:0', dtype=torch.float32, lanes_per_env=lanes)
+    spec = dataclasses.replace(spec, chart_mode=1 if CHART == 'canonical' else 0)
+    env = BatchedAtacomEnv(name, B, device='cuda:0', dtype=torch.float32, lanes_per_env=lanes, chart_mode=CHART)
     nq, ng = spec.dim_q, spec.n_g
     st0 = env.get_state().cpu().numpy().astype(np.float64)
     rng = np.random.default_rng(11)
@@ -38,7 +42,7 @@ for name, spec in (('circle', osc.circle_spec()), ('planar', osc.planar_spec()),
     E, S = np.array(rec.err), np.array(rec.sens)
     M, K = np.array(M), np.array(K)
     ratio = E / (C_SENS * S + FLOOR)
-    print('== %s, %d lanes per env: %d env-steps' % (name, lanes, E.size))
+    print('== %s, %s chart, %d lanes per env: %d env-steps' % (name, CHART, lanes, E.size))
     print('   err: median %.2e  p99 %.2e  p99.9 %.2e  max %.2e' % (np.median(E), np.quantile(E, .99), np.quantile(E, .999), E.max()))
     print('   quick sens (6 draws): median %.2e  p99 %.2e  max %.2e' % (np.median(S), np.quantile(S, .99), S.max()))
     print('   err / (C sens + floor): median %.3f  p99 %.3f  p99.9 %.3f  max %.3f ; above 1 (go to the deep probe): %d'
