@@ -301,6 +301,8 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
     int n_acc = 0;
     static_for<0, NQ>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
+        // (joints NK ... NQ - 1 are looked at only while a free coordinate is missing: wave-uniform skip)
+        if (j >= NK && __builtin_amdgcn_ballot_w64(n_acc < NK) == 0ull) return;
         T w[N1], g[N1];
         T dj = T(0);
 #pragma unroll
@@ -666,6 +668,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
     int n_acc = 0;
     static_for<0, NQ>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
+        if (j >= NK && __builtin_amdgcn_ballot_w64(n_acc < NK) == 0ull) return;
         T w[N1], g[S];
         T dj = T(0);
 #pragma unroll
@@ -818,6 +821,9 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
             beta[i] = qbcast<i % LG, LG>(bl[i / LG]);
             Ua[i] = qbcast<i % LG, LG>(Ul[i / LG]);
         });
+        // (per row on purpose: the column that passes here is typically a LATE one -- the slack of a joint limit, column
+        // 16 of 17 in the iiwa chart (0, 1, 2, 3, 16) -- so a per-lane first-fit scan runs ten trips before it: measured
+        // 4 - 5 us per execution against 1.3 us for testing all eleven columns side by side)
         T fd[NG], res[NG], val[NG];
         bool pick[NG];
         bool any = false;
