@@ -19,9 +19,10 @@ lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 T = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 CHART = os.environ.get('MB_CHART', 'reference')
+DTYPE = torch.float64 if os.environ.get('MB_DTYPE') == 'f64' else torch.float32     # f64: the errors alone are the result
 for name, spec in (('circle', osc.circle_spec()), ('planar', osc.planar_spec()), ('iiwa', osc.iiwa_spec())):
     spec = dataclasses.replace(spec, chart_mode=1 if CHART == 'canonical' else 0)
-    env = BatchedAtacomEnv(name, B, device='cuda:0', dtype=torch.float32, lanes_per_env=lanes, chart_mode=CHART)
+    env = BatchedAtacomEnv(name, B, device='cuda:0', dtype=DTYPE, lanes_per_env=lanes, chart_mode=CHART)
     nq, ng = spec.dim_q, spec.n_g
     st0 = env.get_state().cpu().numpy().astype(np.float64)
     rng = np.random.default_rng(11)
@@ -42,7 +43,7 @@ for name, spec in (('circle', osc.circle_spec()), ('planar', osc.planar_spec()),
     E, S = np.array(rec.err), np.array(rec.sens)
     M, K = np.array(M), np.array(K)
     ratio = E / (C_SENS * S + FLOOR)
-    print('== %s, %s chart, %d lanes per env: %d env-steps' % (name, CHART, lanes, E.size))
+    print('== %s, %s chart, %d lanes per env, %s: %d env-steps' % (name, CHART, lanes, str(DTYPE).split('.')[-1], E.size))
     print('   err: median %.2e  p99 %.2e  p99.9 %.2e  max %.2e' % (np.median(E), np.quantile(E, .99), np.quantile(E, .999), E.max()))
     print('   quick sens (6 draws): median %.2e  p99 %.2e  max %.2e' % (np.median(S), np.quantile(S, .99), S.max()))
     print('   err / (C sens + floor): median %.3f  p99 %.3f  p99.9 %.3f  max %.3f ; above 1 (go to the deep probe): %d'
@@ -54,5 +55,8 @@ for name, spec in (('circle', osc.circle_spec()), ('planar', osc.planar_spec()),
             m = (M >= lo) & (M < hi)
             if m.any():
                 print('     margin [%.0e, %.0e): %7d samples, err max %.2e p99 %.2e' % (lo, hi, m.sum(), E[m].max(), np.quantile(E[m], .99)))
+    if DTYPE == torch.float64:
+        env.close()
+        continue
     print('   ' + rec.finish('verdict'))
     env.close()
