@@ -25,6 +25,10 @@ Golden sets:
                     xml.etree -- no hand-unrolled constant): position, 6 x n LOCAL_WORLD_ALIGNED Jacobian, w x v and
                     exact dJ/dt dq of the three constraint frames (tip = joint 7 + 0.585 z, link_4, link_7), joint
                     limits; + rigid-body dynamics of the same file (mass matrix, inverse dynamics) for row N4
+  G12 chart         the reference's own pinv_null + rref(tol = 0.05) + the two products of atacom.py:127-133 on J_c systems
+                    taken from oracle rollouts of the three tasks (the states the engine visits): mu, the rref'd basis,
+                    max |J_c N| -- what the opt-in canonical chart (oracle/canonical_chart.py, csrc/atacom_chart.h) must
+                    reproduce wherever the reference zeroed nothing and chose the same free coordinates
 """
 import os
 import sys
@@ -541,8 +545,30 @@ def gen_urdf():
     print('iiwa_urdf.npz', {k: v.shape for k, v in out.items() if k.endswith('_J') or k.startswith('dyn_M')})
 
 
+def gen_chart():
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import chart_cases                                           # (ours) J_c systems from oracle rollouts
+    rng = np.random.default_rng(20260929)
+    out = {}
+    for name, (c, n, k) in SHAPES.items():
+        sy = chart_cases.rollout_systems(name, B=64, T=30, seed=3, stride=1)
+        idx = np.sort(rng.choice(len(sy['Jc']), min(300, len(sy['Jc'])), replace=False))
+        Jc, y = sy['Jc'][idx], sy['y'][idx]
+        alpha = rng.uniform(-10, 10, (len(idx), k))
+        mu, Nr = [], []
+        for m, rhs, a in zip(Jc, y, alpha):
+            B, Q = pinv_null(m)                                  # null_space_coordinate.py:8-26
+            N = rref(Q[:, :k], row_vectors=False, tol=0.05)      # atacom.py:128
+            mu.append(-B @ rhs + N @ a)                          # atacom.py:127-133 (psi + Kc c folded into rhs)
+            Nr.append(N)
+        out[name + '_Jc'], out[name + '_y'], out[name + '_alpha'] = Jc, y, alpha
+        out[name + '_mu'], out[name + '_N'] = np.array(mu), np.array(Nr)
+    np.savez_compressed(os.path.join(OUT, 'chart_reference.npz'), **out)
+    print('chart_reference.npz', {k_: v.shape for k_, v in out.items()})
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    todo = sys.argv[1:] or ['nullspace', 'constraints', 'circle', 'generic', 'tables', 'policy', 'baselines', 'urdf', 'circle_dt']
+    todo = sys.argv[1:] or ['nullspace', 'constraints', 'circle', 'generic', 'tables', 'policy', 'baselines', 'urdf', 'circle_dt', 'chart']
     for name in todo:
         globals()['gen_' + name]()

@@ -93,3 +93,26 @@ def jc_of(A, s, nf):
     Jc[:, :, :nq] = A
     Jc[:, nf + np.arange(ng), nq + np.arange(ng)] = s
     return Jc
+
+
+def reference_golden(name):
+    """Golden set G12 (tests/golden/chart_reference.npz, oracle/gen_golden.py:gen_chart): J_c systems with what the
+    REFERENCE's own pinv_null + rref(tol = 0.05) + atacom.py:127-133 computed for them.
+    -> dict(A, s, y, alpha, mu, N, Jc, exact [n] = the reference zeroed nothing (J_c N = 0),
+            free [n, k] = the free ("pivot") coordinates of its reduced echelon basis (-1: not in that form))."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'chart_reference.npz'))
+    spec = SPECS[name]()
+    nq, nf, ng = spec.dim_q, spec.n_f, spec.n_g
+    Jc, N = g[name + '_Jc'], g[name + '_N']
+    k = N.shape[2]
+    resid = np.abs(np.einsum('bcn,bnk->bck', Jc, N)).max((1, 2))
+    free = np.full((len(Jc), k), -1)
+    for b in range(len(Jc)):
+        for i in range(k):
+            rows = [r for r in range(N.shape[1]) if N[b, r, i] == 1.0 and np.count_nonzero(N[b, r]) == 1]
+            if rows:
+                free[b, i] = rows[0]
+    return {'A': Jc[:, :, :nq].copy(), 's': Jc[:, nf + np.arange(ng), nq + np.arange(ng)].copy(), 'y': g[name + '_y'],
+            'alpha': g[name + '_alpha'], 'mu': g[name + '_mu'], 'N': N, 'Jc': Jc, 'exact': resid < 1e-9, 'free': free,
+            'spec': spec}

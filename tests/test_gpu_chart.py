@@ -143,6 +143,31 @@ def _teacher_forced(name, B, T):
     return _TF[name]
 
 
+@pytest.mark.parametrize('name', ['circle', 'planar', 'iiwa'])
+def test_canonical_mu_primitive_against_the_references_own_outputs(name):
+    """Golden set G12 through the C ABI: atacom_canonical_mu (float64 kernel) on J_c systems for which the imported
+    reference's pinv_null + rref(tol = 0.05) + atacom.py:127-133 were recorded.  Wherever the reference zeroed nothing and
+    its reduced echelon basis sits on the same free coordinates, the device's mu IS the reference's (1e-8); the free
+    coordinates are read off the device's own null basis (unit rows), not taken from the oracle."""
+    from chart_cases import reference_golden
+    g = reference_golden(name)
+    A, s, y, alpha = g['A'], g['s'], g['y'], g['alpha']
+    n, k = alpha.shape
+    dev = _dev_mu(name, 'f64', A, s, y, alpha)
+    N = np.stack([_dev_mu(name, 'f64', A, s, np.zeros_like(y), np.eye(k)[i][None].repeat(n, 0)) for i in range(k)], 2)
+    assert np.abs(np.einsum('bcn,bnk->bck', g['Jc'], N)).max() < 1e-8          # the device's basis: exact on every system
+    free = np.full((n, k), -1)
+    for b in range(n):
+        for i in range(k):
+            rows = [r for r in range(N.shape[1]) if abs(N[b, r, i] - 1.0) < 1e-12 and (np.abs(N[b, r]) > 1e-12).sum() == 1]
+            free[b, i] = rows[0] if rows else -1
+    same = g['exact'] & (free == g['free']).all(1)
+    assert same.mean() > {'circle': 0.03, 'planar': 0.9, 'iiwa': 0.5}[name], same.mean()
+    err = np.abs(dev - g['mu']).max(1) / np.maximum(1.0, np.abs(g['mu']).max(1))
+    print('%s: %d of %d systems comparable, max err %.2e' % (name, same.sum(), n, err[same].max()))
+    assert err[same].max() < 1e-8
+
+
 @pytest.mark.parametrize('lanes', [1, 2, 4, 8])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 @pytest.mark.parametrize('name', ['circle', 'planar', 'iiwa'])
