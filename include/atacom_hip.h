@@ -102,6 +102,14 @@ typedef struct atacom_config {
                                      test ||P_S e_j|| > rref_tol, nothing is ever zeroed (N is an exact null basis on every
                                      state) and no factorisation of Jc is needed (rl_on_manifold_amd/csrc/atacom_chart.h;
                                      specification oracle/canonical_chart.py).  ATACOM environments only. */
+    int32_t task;                 /* ATACOM_ENV_PLANAR only: 0 = hitting (task 'H', AirHockeyHit -- the default and the BASELINE
+                                     configuration), 1 = defending (task 'D', atacom_air_hockey.py:22-27 -> mushroom_rl's
+                                     AirHockeyDefend [upstream, restated from memory -- not in the reference tree]: the puck
+                                     starts in the opponent's half moving towards the agent's goal; has_hit latches on
+                                     mallet contact, has_bounce on the agent-side end rims; absorbing when the puck is back
+                                     in the opponent's half after either, -50 for conceding a goal).  The reference's iiwa
+                                     wrapper raises NotImplementedError for 'D' (iiwa_hit_atacom.py:20-21), so does this */
+    int32_t reserved0;            /* keep 0 */
     double dt_base;               /* time step of the BASE environment's integrator when it differs from `dt` (0 = same).
                                      The reference's CircleEnvAtacom / CircleEnvErrorCorrection hand time_step to the wrapper
                                      only -- slack integration, atacom.py:135 -- while the base CircularMotion keeps its

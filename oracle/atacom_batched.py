@@ -16,7 +16,7 @@ import numpy as np
 
 from . import robots
 from .atacom_scalar import (ENV_CIRCLE, ENV_PLANAR, ENV_IIWA, TABLE_LENGTH, TABLE_WIDTH, GOAL_WIDTH,
-                            MALLET_RADIUS, PUCK_RADIUS, UNIVERSAL_HEIGHT, HIT_RANGE, GOAL_POS, E_MALLET, E_RIM,
+                            MALLET_RADIUS, PUCK_RADIUS, UNIVERSAL_HEIGHT, HIT_RANGE, GOAL_POS, E_MALLET, E_RIM, DEFEND_START_RANGE,
                             MODE_ATACOM, MODE_ERROR_CORRECTION, MODE_TERMINATED)
 
 
@@ -219,8 +219,13 @@ class BatchedAtacomEnv:
         self.init_q = np.broadcast_to(np.asarray(init_q, dtype=np.float64), (batch, nq)).copy()
         self.init_dq = np.zeros((batch, nq)) if init_dq is None else \
             np.broadcast_to(np.asarray(init_dq, dtype=np.float64), (batch, nq)).copy()
-        pk = np.array([HIT_RANGE[0].mean(), HIT_RANGE[1].mean(), 0, 0, 0, 0.0]) if init_puck is None \
-            else np.asarray(init_puck, dtype=np.float64)
+        self.defend = spec.env_id == ENV_PLANAR and getattr(spec, 'task', 0) == 1
+        if init_puck is not None:
+            pk = np.asarray(init_puck, dtype=np.float64)
+        elif self.defend:           # AirHockeyDefend.setup [upstream]: middle of start_range in x, y = 0, velocity (-1, 0)
+            pk = np.array([DEFEND_START_RANGE[0].mean(), 0.0, 0, -1.0, 0, 0.0])
+        else:
+            pk = np.array([HIT_RANGE[0].mean(), HIT_RANGE[1].mean(), 0, 0, 0, 0.0])
         self.init_puck = np.broadcast_to(pk, (batch, 6)).copy()
         self.q = np.zeros((batch, nq))
         self.dq = np.zeros((batch, nq))
@@ -230,6 +235,7 @@ class BatchedAtacomEnv:
         self.qx = np.zeros((batch, 3))
         self.dqx = np.zeros((batch, 3))
         self.has_hit = np.zeros(batch, dtype=bool)
+        self.has_bounce = np.zeros(batch, dtype=bool)       # task 'D' only
         self.r_hit = np.zeros(batch)
         self.vel_hit_x = np.zeros(batch)
         self.t = np.zeros(batch, dtype=np.int64)
@@ -249,10 +255,11 @@ class BatchedAtacomEnv:
         m = np.ones(self.B, dtype=bool) if mask is None else np.asarray(mask, dtype=bool)
         self.q[m], self.dq[m], self.puck[m] = self.init_q[m], self.init_dq[m], self.init_puck[m]
         self.has_hit[m], self.r_hit[m], self.vel_hit_x[m], self.t[m] = False, 0.0, 0.0, 0
+        self.has_bounce[m] = False
         self.qx[m], self.dqx[m] = 0.0, 0.0
         if self.random_init and m.any():
             env, ep = np.arange(self.B)[m], self.episode[m]
-            u = [device_uniform(self.seed, env, ep, i) for i in range(4)]
+            u = [device_uniform(self.seed, env, ep, i) for i in range(5)]
             if self.spec.env_id == ENV_CIRCLE:              # circle_base.py:36-42
                 y = -0.5 + 1.5 * u[0]
                 x = np.sqrt(np.maximum(1 - y * y, 0)) * np.where(u[1] < 0.5, -1.0, 1.0)
@@ -261,6 +268,13 @@ class BatchedAtacomEnv:
                 sp = u[3] / np.sqrt(dx * dx + dy * dy)
                 self.q[m] = np.stack([x, y], -1)
                 self.dq[m] = np.stack([dx * sp, dy * sp], -1)
+            elif self.defend:                               # AirHockeyDefend.setup [upstream]
+                self.puck[m, 0] = 0.25 + 0.4 * u[0]
+                self.puck[m, 1] = -0.4 + 0.8 * u[1]
+                v, ang = 1.0 + 1.2 * u[2], -0.5 + u[3]
+                self.puck[m, 3] = -np.cos(ang) * v
+                self.puck[m, 4] = np.sin(ang) * v
+                self.puck[m, 5] = -1.0 + 2.0 * u[4]
             else:                                           # env_hitting.py:24-25
                 self.puck[m, 0] = -0.6 + 0.4 * u[0]
                 self.puck[m, 1] = -0.4 + 0.8 * u[1]
@@ -482,6 +496,12 @@ class BatchedAtacomEnv:
         sg = np.sign(pk[:, 0])
         pk[:, 0] = np.where(ox, sg * (2 * xlim - np.abs(pk[:, 0])), pk[:, 0])
         pk[:, 3] = np.where(ox & (pk[:, 3] * sg > 0), -E_RIM * pk[:, 3], pk[:, 3])
+        if self.defend:
+            # AirHockeyDefend._simulation_post_step [upstream]: has_hit latches on puck / mallet contact, has_bounce on
+            # contact with the end rims of the agent's side (t_down_rim_l / _r)
+            self.has_hit |= hit
+            self.has_bounce |= ox & (sg < 0)
+            return
         v = np.hypot(pk[:, 3], pk[:, 4])
         self._cm(v - 0.1, ~self.has_hit)
         new_hit = (~self.has_hit) & (v > 0.1)
@@ -495,13 +515,42 @@ class BatchedAtacomEnv:
         mal = np.abs(mallet_xy_world(sp, self.q)) - bnd
         out |= np.any(mal > 0.02, -1)
         spd = np.hypot(self.puck[:, 3], self.puck[:, 4])
-        out |= self.has_hit & (spd < 0.01)
         self._cm((np.abs(self.puck[:, :2]) - bnd).T[0]); self._cm((np.abs(self.puck[:, :2]) - bnd).T[1])
         self._cm(mal[:, 0] - 0.02); self._cm(mal[:, 1] - 0.02)
+        if self.defend:             # AirHockeyDefend.is_absorbing [upstream]: hit or bounced, and back in the other half
+            out |= (self.has_hit | self.has_bounce) & (self.puck[:, 0] > 0)
+            self._cm(self.puck[:, 0], self.has_hit | self.has_bounce)
+            return out
+        out |= self.has_hit & (spd < 0.01)
         self._cm(spd - 0.01, self.has_hit)
         return out
 
+    def _reward_defend(self, alpha, absorbing):
+        """AirHockeyDefend.reward [upstream, restated from memory -- mushroom_rl is not in the reference tree]:
+        absorbing: -50 if the puck is in the agent's goal, else 0; has_bounce: -1; has_hit: r_x + r_y + r_vel + 1 while the puck
+        is in -0.8 < x < -0.4 (resting near x = -0.6, y = 0), else 0; before the hit: the mallet on the line x = -0.6 at the
+        puck's y (0.3 exp(-3 |dx|) + 0.7 N(|dy| - 0.08; sigma 0.2) / 2)."""
+        sp = self.spec
+        pp, pv = self.puck[:, :2], self.puck[:, 3:5]
+        conceded = (pp[:, 0] + TABLE_LENGTH / 2 < 0) & (np.abs(pp[:, 1]) - GOAL_WIDTH < 0)
+        self._cm(np.abs(pp[:, 1]) - GOAL_WIDTH, absorbing & (pp[:, 0] + TABLE_LENGTH / 2 < 0))
+        r_y = 3 * np.exp(-3 * np.abs(pp[:, 1]))
+        r_x = np.exp(-5 * np.abs(pp[:, 0] + 0.6))
+        r_vel = 5 * np.exp(-25 * (pv * pv).sum(-1))
+        zone = (pp[:, 0] > -0.8) & (pp[:, 0] < -0.4)
+        self._cm(pp[:, 0] + 0.8, self.has_hit & ~self.has_bounce); self._cm(pp[:, 0] + 0.4, self.has_hit & ~self.has_bounce)
+        r_hit = np.where(zone, r_x + r_y + r_vel + 1, 0.0)
+        ee = mallet_xy_world(sp, self.q)
+        ex, ey = np.abs(-0.6 - ee[:, 0]), np.abs(pp[:, 1] - ee[:, 1])
+        sig = 0.2
+        r_app = 0.3 * np.exp(-3 * ex) + 0.7 * (np.exp(-((ey - 0.08) / sig) ** 2 / 2) / (np.sqrt(2 * np.pi) * sig) / 2)
+        r = np.where(absorbing, np.where(conceded, -50.0, 0.0),
+                     np.where(self.has_bounce, -1.0, np.where(self.has_hit, r_hit, r_app)))
+        return r - sp.action_penalty * np.sqrt((alpha * alpha).sum(-1))
+
     def _reward(self, alpha, absorbing):
+        if self.defend:
+            return self._reward_defend(alpha, absorbing)
         sp = self.spec
         pp = self.puck[:, :2]
         goal = (pp[:, 0] - TABLE_LENGTH / 2 > 0) & (np.abs(pp[:, 1]) - GOAL_WIDTH < 0)

@@ -28,6 +28,7 @@ TABLE_LENGTH, TABLE_WIDTH, GOAL_WIDTH = 1.96, 1.02, 0.25
 PUCK_RADIUS, MALLET_RADIUS, UNIVERSAL_HEIGHT = 0.03165, 0.05, 0.1505
 HIT_RANGE = np.array([[-0.6, -0.2], [-0.4, 0.4]])      # env_hitting.py:11
 GOAL_POS = np.array([0.98, 0.0])                        # env_hitting.py:12
+DEFEND_START_RANGE = np.array([[0.25, 0.65], [-0.4, 0.4]])   # mushroom_rl AirHockeyDefend.start_range [upstream]
 # contact model of this build (row N1; Bullet's is unpinned): restitution of mallet / rim contacts
 E_MALLET, E_RIM = 0.8, 0.8
 
@@ -60,6 +61,8 @@ class EnvSpec:
                              # base CircularMotion keeps its default 0.01); 0 = same as dt
     chart_mode: int = 0      # 0: the reference's chart (LAPACK null basis + rref with tolerance); 1: the canonical chart
                              # (oracle/canonical_chart.py; opt-in) -- batched oracle only
+    task: int = 0            # planar: 0 = hitting ('H'), 1 = defending ('D', atacom_air_hockey.py:22-27 -> mushroom_rl's
+                             # AirHockeyDefend [upstream, restated from memory]) -- batched oracle only
     dynamics_mode: int = 0   # 0: inverse o forward dynamics = identity; 1: rigid body (row N4, iiwa,
                              # oracle/dynamics.py -- implemented by the batched oracle only)
 
@@ -108,14 +111,14 @@ def circle_t_spec(horizon=500, gamma=0.99, dt=0.01, tol=0.1):
     return sp
 
 
-def planar_spec(horizon=120, gamma=0.99, Kc=240.0, dt=1 / 240.0, substeps=4, bias_mode='reference'):
+def planar_spec(horizon=120, gamma=0.99, Kc=240.0, dt=1 / 240.0, substeps=4, bias_mode='reference', task=0):
     """atacom_air_hockey.py:28-43 (Kq = 2 acc_max / vel_max)."""
     acc = np.full(3, 10.0)
     vel = robots.PLANAR_VEL_LIMIT.copy()
     return EnvSpec(ENV_PLANAR, 3, 0, 6, K=np.array([0.5] * 3 + [1.0] * 3), Kc=np.full(6, float(Kc)),
                    vel_max=vel, acc_max=acc, Kq=2 * acc / vel, dt=dt, substeps=substeps,
                    horizon=horizon, gamma=gamma, obs_dim=12, bias_mode=bias_mode,
-                   base_xy=robots.PLANAR_BASE_XYZ[:2].copy())
+                   base_xy=robots.PLANAR_BASE_XYZ[:2].copy(), task=task)
 
 
 def iiwa_spec(horizon=120, gamma=0.99, Kc=240.0, dt=1 / 240.0, substeps=4, bias_mode='reference', dynamics_mode=0):

@@ -29,7 +29,8 @@ class AtacomConfig(C.Structure):
                 ('K', C.c_double * MAX_C), ('Kc', C.c_double * MAX_C), ('vel_max', C.c_double * MAX_Q),
                 ('acc_max', C.c_double * MAX_Q), ('Kq', C.c_double * MAX_Q), ('pos_limit', C.c_double * MAX_Q),
                 ('base_xy', C.c_double * 2), ('link', C.c_double * 3), ('term_tol', C.c_double), ('random_init', C.c_int32), ('seed', C.c_int32),
-                ('dynamics_mode', C.c_int32), ('chart_mode', C.c_int32), ('dt_base', C.c_double)]
+                ('dynamics_mode', C.c_int32), ('chart_mode', C.c_int32), ('task', C.c_int32), ('reserved0', C.c_int32),
+                ('dt_base', C.c_double)]
 
 
 class AtacomMlp(C.Structure):

@@ -107,8 +107,11 @@ int pick_lanes(const atacom_config& c, int kind) {
 }
 
 // default initial state rows: [q, dq, puck(6)]
-void default_init_row(int env_id, std::vector<double>& row) {
-    const double puck[6] = {-0.4, 0.0, 0.0, 0.0, 0.0, 0.0};   // centre of hit_range, env_hitting.py:11,27
+void default_init_row(int env_id, int task, std::vector<double>& row) {
+    double puck[6] = {-0.4, 0.0, 0.0, 0.0, 0.0, 0.0};         // centre of hit_range, env_hitting.py:11,27
+    if (env_id == ATACOM_ENV_PLANAR && task == 1) {           // AirHockeyDefend [upstream]: middle of start_range's x, y = 0,
+        puck[0] = 0.45; puck[3] = -1.0;                       // velocity (-1, 0)
+    }
     if (env_id == ATACOM_ENV_CIRCLE || env_id == ATACOM_ENV_CIRCLE_EC || env_id == ATACOM_ENV_CIRCLE_T) {
         row = {-1.0, 0.0, 0.0, 0.0};                            // circle_base.py:44
     } else if (env_id == ATACOM_ENV_PLANAR) {
@@ -253,6 +256,10 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
         return fail(ATACOM_E_INVALID, "atacom_create: dynamics_mode 1 / 2 (rigid body) exist for ATACOM_ENV_IIWA only");
     if (cfg->chart_mode != 0 && cfg->chart_mode != 1)
         return fail(ATACOM_E_INVALID, "atacom_create: chart_mode must be 0 (reference) or 1 (canonical)");
+    if (cfg->task != 0 && !(cfg->task == 1 && cfg->env_id == ATACOM_ENV_PLANAR))
+        return fail(ATACOM_E_UNSUPPORTED, "atacom_create: task 1 (defend) exists for ATACOM_ENV_PLANAR only "
+                                          "(the reference's iiwa wrapper raises NotImplementedError, iiwa_hit_atacom.py:20-21)");
+    if (cfg->reserved0 != 0) return fail(ATACOM_E_INVALID, "atacom_create: reserved0 must be 0");
     if (cfg->chart_mode == 1 && cfg->env_id != ATACOM_ENV_CIRCLE && cfg->env_id != ATACOM_ENV_PLANAR &&
         cfg->env_id != ATACOM_ENV_IIWA)
         return fail(ATACOM_E_INVALID, "atacom_create: chart_mode 1 needs an ATACOM environment (the E / T baselines have no chart)");
@@ -270,7 +277,7 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
     void* drow = nullptr;
     // default initial state for every env, then a full reset
     std::vector<double> row;
-    default_init_row(cfg->env_id, row);
+    default_init_row(cfg->env_id, cfg->task, row);
     std::vector<char> bytes(row.size() * ops->elem);
     for (size_t i = 0; i < row.size(); ++i) {
         if (ops->elem == 4) reinterpret_cast<float*>(bytes.data())[i] = (float)row[i];

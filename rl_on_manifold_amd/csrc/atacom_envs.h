@@ -46,6 +46,7 @@ struct Iiwa {
 template <typename T>
 struct Params {
     int batch, substeps, horizon, hold_q, bias_mode, auto_reset, random_init, dynamics_mode;
+    int task;                  // planar: 0 = hit, 1 = defend (atacom_air_hockey.py:22-27)
     unsigned int seed;
     T dt, dt_base, rref_tol, action_penalty, alpha_max;      // dt_base: the base env's integrator step (circle quirk Q4)
     T K[12], Kc[12], vel_max[6], acc_max[6], Kq[6], pos_limit[6];

@@ -232,8 +232,22 @@ __device__ __forceinline__ void reset_env(const Params<T>& P, const T* __restric
         slack_init<T, E>(P, st);
     } else {
         // env_hitting.py:24-25: puck uniform in hit_range = [-0.6, -0.2] x [-0.4, 0.4] (env_hitting.py:11)
+        if (E::ID == 1 && P.task == 1) {
+            // task 'D', AirHockeyDefend.setup [upstream]: puck uniform in start_range = [0.25, 0.65] x [-0.4, 0.4], speed
+            // uniform in init_velocity_range = (1, 2.2) towards the agent within +-0.5 rad, yaw rate uniform in (-1, 1)
+            st.puck[0] = T(0.25) + T(0.4) * device_uniform<T>(P.seed, b, ep, 0);
+            st.puck[1] = T(-0.4) + T(0.8) * device_uniform<T>(P.seed, b, ep, 1);
+            const T v = T(1) + T(1.2) * device_uniform<T>(P.seed, b, ep, 2);
+            const T ang = T(-0.5) + device_uniform<T>(P.seed, b, ep, 3);
+            T sa, ca;
+            num<T>::sincos(ang, &sa, &ca);
+            st.puck[3] = -ca * v;
+            st.puck[4] = sa * v;
+            st.puck[5] = T(-1) + T(2) * device_uniform<T>(P.seed, b, ep, 4);
+        } else {
         st.puck[0] = T(-0.6) + T(0.4) * device_uniform<T>(P.seed, b, ep, 0);
         st.puck[1] = T(-0.4) + T(0.8) * device_uniform<T>(P.seed, b, ep, 1);
+        }
     }
 }
 
@@ -601,17 +615,25 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                     st.puck[1] = oy ? sg * (T(2) * ylim - ay) : st.puck[1];
                     st.puck[4] = (oy && st.puck[4] * sg > T(0)) ? -P.e_rim * st.puck[4] : st.puck[4];
                 }
+                bool own_rim;   // the puck met the end rim on the agent's side (x < 0) in this sub-step
                 {   // end rims, open in the goal mouth
                     const T ax = num<T>::abs(st.puck[0]);
                     const bool ox = (ax > xlim) && (num<T>::abs(st.puck[1]) >= P.goal_w);
                     const T sg = st.puck[0] > T(0) ? T(1) : (st.puck[0] < T(0) ? T(-1) : T(0));
+                    own_rim = ox && (sg < T(0));
                     st.puck[0] = ox ? sg * (T(2) * xlim - ax) : st.puck[0];
                     st.puck[3] = (ox && st.puck[3] * sg > T(0)) ? -P.e_rim * st.puck[3] : st.puck[3];
                 }
-                const T pv2k = num<T>::fma(st.puck[3], st.puck[3], st.puck[4] * st.puck[4]);
-                const bool new_hit = (st.has_hit == 0) && (pv2k > T(0.01));      // env_hitting.py:80-85
-                st.vel_hit_x = new_hit ? st.puck[3] : st.vel_hit_x;
-                st.has_hit = new_hit ? 1 : st.has_hit;
+                if (E::ID == 1 && P.task == 1) {
+                    // task 'D' (AirHockeyDefend._simulation_post_step [upstream]): has_hit (bit 0) latches on puck / mallet
+                    // contact, has_bounce (bit 1) on contact with the end rims of the agent's side
+                    st.has_hit |= (hit ? 1 : 0) | (own_rim ? 2 : 0);
+                } else {
+                    const T pv2k = num<T>::fma(st.puck[3], st.puck[3], st.puck[4] * st.puck[4]);
+                    const bool new_hit = (st.has_hit == 0) && (pv2k > T(0.01));      // env_hitting.py:80-85
+                    st.vel_hit_x = new_hit ? st.puck[3] : st.vel_hit_x;
+                    st.has_hit = new_hit ? 1 : st.has_hit;
+                }
             }
         }
         ATACOM_MARK("POST_reward");
@@ -619,6 +641,26 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
         const T pv2 = num<T>::fma(st.puck[3], st.puck[3], st.puck[4] * st.puck[4]);
         bool ab = (num<T>::abs(st.puck[0]) > P.table_hx) || (num<T>::abs(st.puck[1]) > P.table_hy);
         ab = ab || (num<T>::abs(mxy[0]) - P.table_hx > T(0.02)) || (num<T>::abs(mxy[1]) - P.table_hy > T(0.02));
+        T r;
+        if (E::ID == 1 && P.task == 1) {
+            // task 'D': AirHockeyDefend.is_absorbing / .reward [upstream, restated from memory; DESIGN.md section 4]
+            ab = ab || ((st.has_hit != 0) && (st.puck[0] > T(0)));             // hit or bounced, and back in the other half
+            const bool conceded = (st.puck[0] + P.table_hx < T(0)) && (num<T>::abs(st.puck[1]) - P.goal_w < T(0));
+            const T apy = num<T>::abs(st.puck[1]);
+            // after a hit: the puck resting near the line x = -0.6 on the agent's side
+            const T r_y = T(3) * num<T>::exp(T(-3) * apy);
+            const T r_x = num<T>::exp(T(-5) * num<T>::abs(st.puck[0] + T(0.6)));
+            const T r_vel = T(5) * num<T>::exp(T(-25) * pv2);
+            const bool zone = (st.puck[0] > T(-0.8)) && (st.puck[0] < T(-0.4));
+            const T r_hit = zone ? ((r_x + r_y) + r_vel) + T(1) : T(0);
+            // before: the mallet on the line x = -0.6 at the puck's y (a Gaussian bump at 0.08 offset)
+            const T ex = num<T>::abs(T(-0.6) - mxy[0]), ey = num<T>::abs(st.puck[1] - mxy[1]);
+            const T u = (ey - T(0.08)) * T(5);                                   // sigma = 0.2
+            const T r_app = num<T>::fma(T(0.3), num<T>::exp(T(-3) * ex),
+                                        T(0.7 * 0.5 * 1.9947114020071635) * num<T>::exp(T(-0.5) * u * u));
+            r = ab ? (conceded ? T(-50) : T(0))
+                   : (((st.has_hit & 2) != 0) ? T(-1) : (((st.has_hit & 1) != 0) ? r_hit : r_app));
+        } else {
         ab = ab || ((st.has_hit != 0) && (pv2 < T(0.0001)));
         // reward: env_hitting.py:39-69
         const bool goal = (st.puck[0] - P.table_hx > T(0)) && (num<T>::abs(st.puck[1]) - P.goal_w < T(0));
@@ -632,7 +674,8 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
         const T r_app = num<T>::exp(T(-8) * (dist - T(0.08))) * cosang;
         const bool upd = !ab && (st.has_hit == 0);
         st.r_hit = upd ? r_app : st.r_hit;
-        T r = ab ? (goal ? T(80) : T(0)) : ((st.has_hit != 0) ? num<T>::fma(st.vel_hit_x, T(0.1), T(1) + st.r_hit) : r_app);
+        r = ab ? (goal ? T(80) : T(0)) : ((st.has_hit != 0) ? num<T>::fma(st.vel_hit_x, T(0.1), T(1) + st.r_hit) : r_app);
+        }
         out.reward = num<T>::fma(-P.action_penalty, num<T>::sqrt(anorm2), r);     // explicit: the same contraction in every kernel
         out.absorbing = ab;
         // constraint statistics, atacom.py:201-205
@@ -1060,7 +1103,8 @@ __global__ void k_set_state(int B, T* __restrict__ f, int* __restrict__ ip, cons
     for (int i = 0; i < E::NG; ++i) st.s[i] = o[k++];
 #pragma unroll
     for (int i = 0; i < 6; ++i) st.puck[i] = o[k++];
-    st.has_hit = (o[k++] != T(0)) ? 1 : 0; st.r_hit = o[k++]; st.vel_hit_x = o[k++]; st.t = (int)o[k++];
+    st.has_hit = ((int)o[k++]) & 3;                 // bit 0 has_hit, bit 1 has_bounce (task 'D')
+    st.r_hit = o[k++]; st.vel_hit_x = o[k++]; st.t = (int)o[k++];
     store_state<T, E>(f, ip, B, b, st);
 }
 

@@ -10,7 +10,7 @@ static Params<T> make_params(const atacom_config& c) {
     Params<T> P;
     P.batch = c.batch; P.substeps = c.substeps; P.horizon = c.horizon; P.hold_q = c.hold_q;
     P.bias_mode = c.bias_mode; P.auto_reset = c.auto_reset;
-    P.random_init = c.random_init; P.seed = (unsigned int)c.seed; P.dynamics_mode = c.dynamics_mode;
+    P.random_init = c.random_init; P.seed = (unsigned int)c.seed; P.dynamics_mode = c.dynamics_mode; P.task = c.task;
     P.dt = (T)c.dt; P.dt_base = (T)(c.dt_base > 0 ? c.dt_base : c.dt); P.rref_tol = (T)c.rref_tol; P.action_penalty = (T)c.action_penalty;
     double amax = c.acc_max[0];
     for (int i = 0; i < ATACOM_MAX_C; ++i) { P.K[i] = (T)c.K[i]; P.Kc[i] = (T)c.Kc[i]; }

@@ -40,7 +40,7 @@ class BatchedAtacomEnv:
     def __init__(self, env, batch, device='cuda:0', dtype=torch.float32, horizon=None, gamma=None, Kc=None,
                  time_step=None, n_intermediate_steps=None, action_penalty=None, auto_reset=False,
                  hold_q=None, bias_mode='reference', rref_tol=None, lanes_per_env=0, term_tol=None, random_init=False, seed=0,
-                 dynamics_mode='kinematic', chart_mode='reference'):
+                 dynamics_mode='kinematic', chart_mode='reference', task='H'):
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.AtacomError("BatchedAtacomEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -90,6 +90,13 @@ class BatchedAtacomEnv:
         if chart_mode not in charts:
             raise ValueError("chart_mode must be one of %s, got %r" % (sorted(charts), chart_mode))
         cfg.chart_mode = charts[chart_mode]
+        # planar only: 'H' hitting (default), 'D' defending (atacom_air_hockey.py:14-27); the reference's iiwa wrapper has no 'D'
+        tasks = {'H': 0, 'D': 1}
+        if task not in tasks:
+            raise ValueError("task must be 'H' or 'D', got %r" % (task,))
+        if task == 'D' and self.env_id != _lib.ENV_PLANAR:
+            raise NotImplementedError("task 'D' exists for the planar environment only (iiwa_hit_atacom.py:20-21 raises too)")
+        cfg.task = tasks[task]
         d = _lib.get_dims(self.env_id)
         self.dims = {'q': d.dim_q, 'f': d.n_f, 'g': d.n_g, 'null': d.n_null, 'c': d.n_f + d.n_g}   # atacom.py:25-40
         self.obs_dim, self.state_dim, self.init_state_dim = d.obs_dim, d.state_dim, d.init_state_dim

@@ -13,6 +13,7 @@ import torch
 
 from .engine import BatchedAtacomEnv
 
+DEFEND_START_RANGE = np.array([[0.25, 0.65], [-0.4, 0.4]])   # mushroom_rl AirHockeyDefend.start_range [upstream]
 HIT_RANGE = np.array([[-0.6, -0.2], [-0.4, 0.4]])      # env_hitting.py:11
 
 
@@ -109,14 +110,17 @@ class CircleEnvTerminated(CircleEnvAtacom):
 class _AirHockeyFacade(_Facade):
     def _init_common(self, task, gamma, horizon, timestep, n_intermediate_steps, env_noise, obs_noise, obs_delay,
                      Kc, random_init, action_penalty, device, dtype):
-        if task != 'H':
-            raise NotImplementedError("only the hitting task 'H' is on the hot path (BASELINE.json configs)")
+        if task not in ('H', 'D'):
+            raise ValueError("task must be 'H' or 'D', got %r" % (task,))
+        if task == 'D' and self._env_name != 'planar':
+            raise NotImplementedError       # as the reference does for the iiwa wrapper (iiwa_hit_atacom.py:20-21)
+        self.task = task
         if env_noise or obs_noise or obs_delay:
             raise NotImplementedError("domain randomisation (env_noise / obs_noise / obs_delay) is out of scope")
         self.random_init = random_init
         self._make(horizon=horizon, gamma=gamma, Kc=Kc, time_step=timestep,
                    n_intermediate_steps=n_intermediate_steps, action_penalty=action_penalty, device=device,
-                   dtype=dtype)
+                   dtype=dtype, task=task)
         st = self._engine.get_state()[0].cpu().numpy()
         nq = self.dims['q']
         self._init_q = st[:nq].astype(np.float64)
@@ -126,11 +130,23 @@ class _AirHockeyFacade(_Facade):
         if state is not None:
             state = np.asarray(state, dtype=np.float64)
         else:
-            if self.random_init:                       # env_hitting.py:24-25
-                puck_pos = np.random.rand(2) * (HIT_RANGE[:, 1] - HIT_RANGE[:, 0]) + HIT_RANGE[:, 0]
-            else:                                      # :27
-                puck_pos = np.mean(HIT_RANGE, axis=1)
-            state = np.concatenate([self._init_q, np.zeros(nq), puck_pos, np.zeros(4)])
+            if self.task == 'D':                       # mushroom_rl AirHockeyDefend.setup [upstream, from memory]
+                if self.random_init:
+                    puck_pos = np.random.rand(2) * (DEFEND_START_RANGE[:, 1] - DEFEND_START_RANGE[:, 0]) \
+                        + DEFEND_START_RANGE[:, 0]
+                    lin_vel = np.random.uniform(1.0, 2.2)
+                    angle = np.random.uniform(-0.5, 0.5)
+                    puck = [puck_pos[0], puck_pos[1], 0.0, -np.cos(angle) * lin_vel, np.sin(angle) * lin_vel,
+                            np.random.uniform(-1, 1)]
+                else:
+                    puck = [DEFEND_START_RANGE[0].mean(), 0.0, 0.0, -1.0, 0.0, 0.0]
+                state = np.concatenate([self._init_q, np.zeros(nq), puck])
+            else:
+                if self.random_init:                   # env_hitting.py:24-25
+                    puck_pos = np.random.rand(2) * (HIT_RANGE[:, 1] - HIT_RANGE[:, 0]) + HIT_RANGE[:, 0]
+                else:                                  # :27
+                    puck_pos = np.mean(HIT_RANGE, axis=1)
+                state = np.concatenate([self._init_q, np.zeros(nq), puck_pos, np.zeros(4)])
         self.state = self._engine.reset(state=state.reshape(1, -1))[0].cpu().numpy().astype(np.float64)
         return self.state
 
