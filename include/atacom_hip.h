@@ -216,6 +216,16 @@ int atacom_get_lanes(const atacom_handle* h, int32_t* out_step_lanes, int32_t* o
 int atacom_get_state(atacom_handle* h, void* d_state, void* stream);
 int atacom_set_state(atacom_handle* h, const void* d_state, void* stream);
 
+/* Checkpoint / resume of the WHOLE persistent state of a handle -- everything atacom_get_state leaves out as well: the stored
+ * initial states, the constraint-statistics accumulators (atacom.py:201-205), the episode counters of the device-side random
+ * reset and the servo joints of the rigid-body mode.  An opaque byte image (device memory, caller-owned, at least
+ * atacom_snapshot_bytes(h) bytes) valid for a handle created from the same atacom_config; two device-to-device copies on
+ * `stream`, no synchronisation.  restore(save(x)) followed by the same calls reproduces the run bit for bit (the reference
+ * has no counterpart: its envs are Python objects one would pickle). */
+int64_t atacom_snapshot_bytes(const atacom_handle* h);
+int atacom_snapshot_save(atacom_handle* h, void* d_image, void* stream);
+int atacom_snapshot_restore(atacom_handle* h, const void* d_image, void* stream);
+
 /* Row N4: the three servo joints of the rigid-body mode (joint 7, striker_joint_1, striker_joint_2):
  * d_aux [batch, 6] = [q7, qu1, qu2, dq7, dqu1, dqu2].  ATACOM_ENV_IIWA handles only. */
 int atacom_get_aux_state(atacom_handle* h, void* d_aux, void* stream);

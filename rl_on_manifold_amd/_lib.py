@@ -14,7 +14,7 @@ ENV_CIRCLE, ENV_PLANAR, ENV_IIWA, ENV_CIRCLE_EC, ENV_CIRCLE_T = 0, 1, 2, 3, 4
 F32, F64 = 0, 1
 MAX_C, MAX_Q = 12, 6
 
-EXPORTS = ['atacom_rollout_mlp', 'atacom_rollout_packed', 'atacom_get_aux_state', 'atacom_set_aux_state',
+EXPORTS = ['atacom_snapshot_bytes', 'atacom_snapshot_save', 'atacom_snapshot_restore', 'atacom_rollout_mlp', 'atacom_rollout_packed', 'atacom_get_aux_state', 'atacom_set_aux_state',
            'atacom_inverse_dynamics', 'atacom_forward_dynamics', 'atacom_default_config', 'atacom_get_dims', 'atacom_create', 'atacom_destroy', 'atacom_reset',
            'atacom_step', 'atacom_rollout', 'atacom_get_stats', 'atacom_get_state', 'atacom_set_state',
            'atacom_nullspace', 'atacom_constraint_terms', 'atacom_step_masked', 'atacom_canonical_mu', 'atacom_last_error', 'atacom_version', 'atacom_get_lanes']
@@ -91,6 +91,9 @@ def load():
     lib.atacom_get_state.argtypes = [vp, vp, vp]
     lib.atacom_set_state.argtypes = [vp, vp, vp]
     lib.atacom_get_aux_state.argtypes = [vp, vp, vp]
+    lib.atacom_snapshot_bytes.argtypes = [vp]
+    lib.atacom_snapshot_save.argtypes = [vp, vp, vp]
+    lib.atacom_snapshot_restore.argtypes = [vp, vp, vp]
     lib.atacom_set_aux_state.argtypes = [vp, vp, vp]
     lib.atacom_inverse_dynamics.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp]
     lib.atacom_forward_dynamics.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp, vp]
@@ -99,8 +102,9 @@ def load():
     lib.atacom_last_error.restype = C.c_char_p
     lib.atacom_version.restype = C.c_char_p
     for name in EXPORTS:
-        if name not in ('atacom_last_error', 'atacom_version'):
+        if name not in ('atacom_last_error', 'atacom_version', 'atacom_snapshot_bytes'):
             getattr(lib, name).restype = C.c_int
+    lib.atacom_snapshot_bytes.restype = C.c_int64
     _lib = lib
     return lib
 

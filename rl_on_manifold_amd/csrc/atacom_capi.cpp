@@ -458,6 +458,34 @@ int atacom_set_state(atacom_handle* h, const void* d_state, void* stream) {
     return ATACOM_OK;
 }
 
+// ---- checkpoint / resume: the image is [float fields | int fields] exactly as the handle holds them
+static size_t snapshot_float_bytes(const atacom_handle* h) {
+    const size_t raw = (size_t)h->ops->elem * h->ops->n_planes * (size_t)h->cfg.batch;
+    return (raw + 15) & ~(size_t)15;
+}
+int64_t atacom_snapshot_bytes(const atacom_handle* h) {
+    if (!h) { fail(ATACOM_E_INVALID, "atacom_snapshot_bytes: null handle"); return ATACOM_E_INVALID; }
+    return (int64_t)(snapshot_float_bytes(h) + sizeof(int) * h->ops->n_iplanes * (size_t)h->cfg.batch);
+}
+int atacom_snapshot_save(atacom_handle* h, void* d_image, void* stream) {
+    if (!h || !d_image) return fail(ATACOM_E_INVALID, "atacom_snapshot_save: null argument");
+    ON_DEVICE(h);
+    const size_t B = (size_t)h->cfg.batch, nf = (size_t)h->ops->elem * h->ops->n_planes * B;
+    HIP_TRY(hipMemcpyAsync(d_image, h->f, nf, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync((char*)d_image + snapshot_float_bytes(h), h->ip, sizeof(int) * h->ops->n_iplanes * B,
+                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return ATACOM_OK;
+}
+int atacom_snapshot_restore(atacom_handle* h, const void* d_image, void* stream) {
+    if (!h || !d_image) return fail(ATACOM_E_INVALID, "atacom_snapshot_restore: null argument");
+    ON_DEVICE(h);
+    const size_t B = (size_t)h->cfg.batch, nf = (size_t)h->ops->elem * h->ops->n_planes * B;
+    HIP_TRY(hipMemcpyAsync(h->f, d_image, nf, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(h->ip, (const char*)d_image + snapshot_float_bytes(h), sizeof(int) * h->ops->n_iplanes * B,
+                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return ATACOM_OK;
+}
+
 int atacom_get_aux_state(atacom_handle* h, void* d_aux, void* stream) {
     if (!h || !d_aux) return fail(ATACOM_E_INVALID, "atacom_get_aux_state: null argument");
     if (h->cfg.env_id != ATACOM_ENV_IIWA) return fail(ATACOM_E_INVALID, "atacom_get_aux_state: ATACOM_ENV_IIWA only");

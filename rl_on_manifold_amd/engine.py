@@ -323,6 +323,30 @@ class BatchedAtacomEnv:
         """The kernel mapping of rollout() / rollout_policy() / rollout_packed() (may differ from step()'s)."""
         return self._lanes()[1]
 
+    def _on_my_device(self, t):
+        return t.device.type == 'cuda' and t.device.index == self._dev_index
+
+    def snapshot(self, out=None):
+        """Checkpoint of the WHOLE persistent state (atacom_snapshot_save): what get_state() returns plus the stored initial
+        states, the constraint-statistics accumulators, the episode counters of the device-side random reset and the servo
+        joints -- an opaque uint8 tensor on the device; `restore(image)` followed by the same calls reproduces the run bit
+        for bit.  Two device-to-device copies on the current stream, no synchronisation."""
+        n = int(self._lib.atacom_snapshot_bytes(self._h))
+        if n < 0:
+            _lib.check(n)
+        if out is None:
+            out = torch.empty((n,), device=self.device, dtype=torch.uint8)
+        elif out.dtype != torch.uint8 or out.numel() < n or not self._on_my_device(out) or not out.is_contiguous():
+            raise ValueError("snapshot buffer must be a contiguous uint8 tensor of >= %d bytes on %s" % (n, self.device))
+        _lib.check(self._lib.atacom_snapshot_save(self._h, _ptr(out), self._stream()))
+        return out
+
+    def restore(self, image):
+        n = int(self._lib.atacom_snapshot_bytes(self._h))
+        if image.dtype != torch.uint8 or image.numel() < n or not self._on_my_device(image) or not image.is_contiguous():
+            raise ValueError("snapshot image must be a contiguous uint8 tensor of >= %d bytes on %s" % (n, self.device))
+        _lib.check(self._lib.atacom_snapshot_restore(self._h, _ptr(image), self._stream()))
+
     def get_constraints_logs(self, clear=True):
         res = (C.c_double * 3)()
         _lib.check(self._lib.atacom_get_stats(self._h, C.byref(res), int(clear), self._stream()))
@@ -389,27 +413,18 @@ class GraphedRollout:
                     'absorbing': torch.empty((T, B), device=dev, dtype=torch.uint8),
                     'last': torch.empty((T, B), device=dev, dtype=torch.uint8)}
         self._none = torch.zeros((B,), device=dev, dtype=torch.uint8)       # reset mask selecting nobody = "observe"
-        saved = env.get_state().clone()
-        aux = env.get_aux_state().clone() if env.env_id == _lib.ENV_IIWA else None
+        saved = env.snapshot()             # everything: state, statistics, episode counters, servo joints
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                                       # warm-up outside the capture (lazy inits)
             for _ in range(warmup):
                 self._body(policy, min(T, 2))
         torch.cuda.current_stream(dev).wait_stream(side)
-        self._restore(saved, aux)
-        self.graph = torch.cuda.CUDAGraph()
+        env.restore(saved)                 # the warm-up ran real steps: undo them completely (statistics and the random
+        self.graph = torch.cuda.CUDAGraph()  # reset's episode counters included -- a replay starts where an eager run would)
         with torch.cuda.graph(self.graph):
             self._body(policy, T)
-        self._restore(saved, aux)                                           # the capture itself does not run the kernels,
-                                                                            # but the warm-up did
-        # NOTE: the warm-up's real steps stay in the constraint statistics and (random_init) in the episode counters, which
-        # set_state does not cover: call get_constraints_logs() after construction if the log must start empty
-
-    def _restore(self, saved, aux):
-        self.env.set_state(saved)
-        if aux is not None:
-            self.env.set_aux_state(aux)
+        env.restore(saved)                 # (the capture itself does not run the kernels)
 
     def _body(self, policy, n):
         env, o = self.env, self.out

@@ -469,3 +469,59 @@ def test_step_into_rejects_what_the_raw_pointers_would_misread():
                      ('reward', torch.empty((B, 1), device=DEV))):
         with pytest.raises(ValueError):
             env.step_into(**dict(good, **{key: bad}))
+
+
+@pytest.mark.parametrize('name,kw', [('circle', {}), ('planar', {'task': 'D'}), ('iiwa', {'dynamics_mode': 'rigid_body'})])
+def test_snapshot_restore_reproduces_the_run_bit_for_bit(name, kw):
+    """atacom_snapshot_save / _restore: the whole persistent state -- what get_state() returns AND the stored initial states,
+    the statistics accumulators, the episode counters of the device-side random reset, the servo joints.  Restore, repeat
+    the same calls: identical outputs, identical statistics (the reference's counterpart would be pickling the env)."""
+    from rl_on_manifold_amd import BatchedAtacomEnv
+    B, T = 700, 40
+    env = BatchedAtacomEnv(name, B, device=DEV, random_init=True, seed=4, auto_reset=True, horizon=15, **kw)
+    env.reset()
+    g = torch.Generator(device='cpu').manual_seed(0)
+    acts = (torch.rand(3, T, B, env.dims['null'], generator=g) * 2 - 1).to(DEV)
+    env.rollout(acts[0])                                     # some history: statistics, several auto-resets
+    image = env.snapshot()
+    assert image.dtype == torch.uint8 and image.numel() == env._lib.atacom_snapshot_bytes(env._h)
+    first = env.rollout(acts[1])
+    logs_first = env.get_constraints_logs()
+    env.rollout(acts[2])                                     # wander off ...
+    env.restore(image)                                       # ... and come back
+    again = env.rollout(acts[1])
+    logs_again = env.get_constraints_logs()
+    for k in first:
+        assert torch.equal(first[k], again[k]), k
+    assert logs_first == logs_again
+    # an image of another configuration is refused by size, not silently mis-read
+    other = BatchedAtacomEnv(name, B + 64, device=DEV, **kw)
+    with pytest.raises(ValueError):
+        other.restore(image)
+
+
+def test_graphed_rollout_leaves_no_warmup_residue():
+    """GraphedRollout warms up with real steps before the capture: they must not stay in the constraint
+    statistics nor shift the device-side random resets -- the first replay equals the rollout kernel of a twin engine that
+    never saw a warm-up, fed with the actions the graph's policy chose, and so do the constraint logs."""
+    from rl_on_manifold_amd import BatchedAtacomEnv, GraphedRollout
+    B, T = 512, 12
+    mk = lambda: BatchedAtacomEnv('planar', B, device=DEV, random_init=True, seed=9, auto_reset=True, horizon=5)
+    a, b = mk(), mk()
+    a.reset(); b.reset()
+    a.get_constraints_logs(); b.get_constraints_logs()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    W = torch.randn((a.obs_dim, 3), device=DEV, generator=g) * 0.5
+    policy = lambda obs: torch.tanh(obs @ W) * 1.2
+    gr = GraphedRollout(a, policy, T)
+    out = gr.replay()
+    torch.cuda.synchronize()
+    nobody = torch.zeros((B,), device=DEV, dtype=torch.uint8)
+    for t in range(T):                                        # the same kernels, launched eagerly on the twin
+        obs = b.reset(mask=nobody)
+        assert torch.equal(out['obs'][t], obs), t             # incl. the re-drawn puck positions after the auto-resets
+        nobs, r, ab, info = b.step(policy(obs))
+        assert torch.equal(out['next_obs'][t], nobs) and torch.equal(out['reward'][t], r), t
+        assert torch.equal(out['absorbing'][t].bool(), ab.bool()) and torch.equal(out['last'][t].bool(), info['last'].bool()), t
+    assert out['last'][4].all() and not torch.equal(out['obs'][5][:, :2], out['obs'][0][:, :2])   # auto-reset, new draw
+    assert a.get_constraints_logs() == b.get_constraints_logs()
