@@ -122,7 +122,8 @@ typedef struct atacom_handle atacom_handle;
 typedef struct atacom_dims {
     int32_t dim_q, n_f, n_g, n_null /* = action dim, atacom.py:39,51 */, obs_dim;
     int32_t state_dim;      /* floats per env in atacom_get_state / atacom_set_state:
-                               [q, dq, s, puck(6), has_hit, r_hit, vel_hit_x, t] */
+                               [q, dq, s, puck(6), has_hit, r_hit, vel_hit_x, t]  (task 'D': the has_hit slot holds
+                               has_hit + 2 has_bounce) */
     int32_t init_state_dim; /* floats per env in atacom_reset's d_init_state: [q, dq] (+ puck(6) for planar/iiwa) */
     int32_t record_dim;     /* floats per (step, env) record of atacom_rollout_packed: 2 obs_dim + n_null + 3 */
 } atacom_dims;
