@@ -36,6 +36,12 @@ namespace atacom {
 #define ATACOM_DBG_COUNT(i)
 #endif
 
+// Group kernels: the constraint ROWS owned by the lanes of a group in slack stage B and in the assembly (1), or every lane
+// working through all of them (0: the first form of round 3, kept for A/B builds: -DATACOM_CHART_ROWDIST=0).
+#ifndef ATACOM_CHART_ROWDIST
+#define ATACOM_CHART_ROWDIST 1
+#endif
+
 template <typename T> struct chart_const {
     static constexpr T THETA = T(3e-2);     // stiff-row threshold (oracle/canonical_chart.py: THETA)
     static constexpr T TINY = T(1e-6);      // below this (relative) slack a row is an equality: w_g -> 0
@@ -512,6 +518,13 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
 // decision is taken on replicated or group-summed values, so the lanes of a group agree bit for bit.
 // Cross-lane traffic: DPP broadcasts / butterfly sums (atacom_quad.h) and, once per slack stage, one ds_bpermute gather of
 // the longest vector (its owner is data dependent).
+// ROW SLOTS (second form of round 3): what the inequality rows contribute one by one -- the NG column tests of slack stage
+// B, the NG slack velocities of the assembly -- is done by the lane that OWNS the row (row g: lane g % LG, slot g / LG),
+// ceil(NG / LG) slots per lane instead of NG rows; the passing columns travel as ONE group-summed number (bit g = column g,
+// disjoint powers of two: exact), first fit is its lowest set bit.  Same arithmetic on the same operands (the blended copies
+// carry exact zeros where the row has structural ones), so the results are bit for bit those of the replicated form
+// (-DATACOM_CHART_ROWDIST=0 builds it for A/B); measured on one box, 8192 environments, T-step kernels: iiwa 8 lanes 21.1 ->
+// 19.8 us per step, 4 lanes 22.0 -> 21.5, 2 lanes 24.9 -> 23.7; planar 4 lanes 9.0 -> 8.1 (profiles/r03_ab_rowslots.log).
 template <typename T>
 __device__ __forceinline__ T lane_gather(T v, int src_lane) {
     if constexpr (sizeof(T) == 4) {
@@ -521,6 +534,18 @@ __device__ __forceinline__ T lane_gather(T v, int src_lane) {
         const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b & 0xffffffffll));
         const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(b >> 32));
         return __builtin_bit_cast(T, ((long long)hi << 32) | (unsigned int)lo);
+    }
+}
+
+// max over the group, in all its lanes (the butterfly of qsum, atacom_quad.h)
+template <int LN, typename T>
+__device__ __forceinline__ T qmax(T v) {
+    const T s1 = num<T>::max(v, dpp_mov<0xB1>(v));
+    if constexpr (LN == 2) return s1;
+    else {
+        const T s2 = num<T>::max(s1, dpp_mov<0x4E>(s1));
+        if constexpr (LN == 4) return s2;
+        else return num<T>::max(s2, dpp_mov<DPP_ROW_HALF_MIRROR>(s2));
     }
 }
 
@@ -544,6 +569,55 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
             if (LG * sl + l < N1) v = num<T>::fma(oh[l], z(LG * sl + l), v);
         return v;
     };
+    // ROW SLOTS (ATACOM_CHART_ROWDIST).  Inequality row g belongs to lane g % LG, slot g / LG: what the rows contribute one
+    // by one -- the eleven tests of slack stage B, the slack velocities of the assembly -- a lane does for ITS rows only
+    // (RS = ceil(NG / LG) slots instead of NG rows), on copies of the row data gathered by one-hot blends; A is held over
+    // the sub-steps of a step (hold_q), so its blend leaves the sub-step loop.  What the group needs to agree on travels
+    // as group sums of values only one lane contributes to (exact), so the lanes still agree bit for bit.
+    constexpr bool ROWDIST = (ATACOM_CHART_ROWDIST != 0) && (NG > LG);
+    constexpr int RS = (NG + LG - 1) / LG;
+    // entry (row slot t, joint i) is structurally zero for every lane of the group
+    auto slot_zero = [](int t, int i) constexpr -> bool {
+        bool z = true;
+        for (int l = 0; l < LG; ++l)
+            if (LG * t + l < NG) z = z && E::jac_zero(NF + LG * t + l, i);
+        return z;
+    };
+    auto ownrow = [&](auto&& z, int t) -> T {               // z(g) of the lane's row in slot t (0: the lane has none)
+        T v = T(0);
+#pragma unroll
+        for (int l = 0; l < LG; ++l)
+            if (LG * t + l < NG) v = num<T>::fma(oh[l], z(LG * t + l), v);
+        return v;
+    };
+    auto ownflag = [&](auto&& z, int t) -> bool {
+        bool v = false;
+#pragma unroll
+        for (int l = 0; l < LG; ++l)
+            if (LG * t + l < NG) v = v || ((lq == l) && z(LG * t + l));
+        return v;
+    };
+    [[maybe_unused]] T Ao[RS][NQ], so[RS], ao[RS], yo[RS], bito[RS];
+    if constexpr (ROWDIST) {
+        T pw = T(0);                                         // 2^lq
+#pragma unroll
+        for (int l = 0; l < LG; ++l) pw = num<T>::fma(oh[l], T(1u << l), pw);
+#pragma unroll
+        for (int t = 0; t < RS; ++t) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                T v = T(0);
+#pragma unroll
+                for (int l = 0; l < LG; ++l)
+                    if (LG * t + l < NG && !E::jac_zero(NF + LG * t + l, i)) v = num<T>::fma(oh[l], A[NF + LG * t + l][i], v);
+                Ao[t][i] = v;
+            }
+            so[t] = ownrow([&](int g) { return s[g]; }, t);
+            ao[t] = ownrow([&](int g) { return arow[g]; }, t);
+            yo[t] = ownrow([&](int g) { return y[NF + g]; }, t);
+            bito[t] = pw * T(1u << (LG * t));                // 2^g of the own row (a lane without a row in the slot never passes)
+        }
+    }
     // ---- replicated prologue: metric of the soft rows, its Cholesky factor
     bool soft[NG], isp[NG];
     bool has_stiff = false;
@@ -767,6 +841,18 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
     // (B) exactly one missing: every v_i = beta_i dhat
     const bool need1 = (n_acc == NK - 1) && !done;
     const T tv_last = alpha[NK - 1];
+    // row slots: the flags of the lane's own rows (stage A, rare, works on the replicated ones)
+    [[maybe_unused]] bool ispo[RS], selo[RS], hro[RS];
+    [[maybe_unused]] T wto[RS];
+    if constexpr (ROWDIST) {
+#pragma unroll
+        for (int t = 0; t < RS; ++t) {
+            ispo[t] = ownflag([&](int g) { return isp[g]; }, t);
+            selo[t] = ownflag([&](int g) { return sel[g]; }, t);
+            wto[t] = ownrow([&](int g) { return wtgt[g]; }, t);
+            hro[t] = (LG * t + LG <= NG) ? true : (lq < NG - LG * t);         // the lane has a row in this slot
+        }
+    }
     // the coordinates, replicated (needed by stage B and by the assembly)
     T xa[N1], Ua[N1];
     auto gather_all = [&]() {
@@ -821,45 +907,97 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
             beta[i] = qbcast<i % LG, LG>(bl[i / LG]);
             Ua[i] = qbcast<i % LG, LG>(Ul[i / LG]);
         });
-        // (per row on purpose: the column that passes here is typically a LATE one -- the slack of a joint limit, column
-        // 16 of 17 in the iiwa chart (0, 1, 2, 3, 16) -- so a per-lane first-fit scan runs ten trips before it: measured
-        // 4 - 5 us per execution against 1.3 us for testing all eleven columns side by side)
-        T fd[NG], res[NG], val[NG];
-        bool pick[NG];
-        bool any = false;
-        T vbest = T(-1);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int r = NF + g;
-            T a = T(0), fu = T(0);
-#pragma unroll
-            for (int i = 0; i < NQ; ++i) {
-                if (E::jac_zero(r, i)) continue;
-                a = num<T>::fma(A[r][i], beta[i], a);
-                fu = num<T>::fma(A[r][i], Ua[i], fu);
-            }
-            fd[g] = isp[g] ? beta[NQ] : a;
-            res[g] = isp[g] ? Ua[NQ] - tv_last : num<T>::fma(s[g], tv_last, fu);
-            val[g] = fd[g] * fd[g];
-            const T thr = tol2 * (isp[g] ? T(1) : s[g] * s[g]);
-            const bool pass = !sel[g] && (tiny(g) || (val[g] > thr));
-            pick[g] = need1 && pass && !any;
-            any = any || pass;
-            vbest = sel[g] ? vbest : num<T>::max(vbest, val[g]);
-        }
-        bool taken = false;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const bool fb = need1 && !any && !taken && !sel[g] && (val[g] == vbest);
-            pick[g] = pick[g] || fb;
-            taken = taken || fb;
-        }
         T fds = T(0), rs = T(0);
+        if constexpr (ROWDIST) {
+            // every lane tests ITS rows; the passing columns of the environment as one number, bit g = column g (a group sum
+            // of disjoint powers of two: exact), first fit = its lowest set bit
+            T fdo[RS], reso[RS], valo[RS], mf = T(0);
+            bool tno[RS];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            fds = pick[g] ? (tiny(g) ? T(0) : fd[g]) : fds; rs = pick[g] ? res[g] : rs;
-            wtgt[g] = pick[g] ? tv_last : wtgt[g];
-            sel[g] = sel[g] || pick[g];
+            for (int t = 0; t < RS; ++t) {
+                T a = T(0), fu = T(0);
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    if (slot_zero(t, i)) continue;
+                    a = num<T>::fma(Ao[t][i], beta[i], a);
+                    fu = num<T>::fma(Ao[t][i], Ua[i], fu);
+                }
+                fdo[t] = ispo[t] ? beta[NQ] : a;
+                reso[t] = ispo[t] ? Ua[NQ] - tv_last : num<T>::fma(so[t], tv_last, fu);
+                valo[t] = fdo[t] * fdo[t];
+                tno[t] = !ispo[t] && (num<T>::abs(so[t]) < CC::TINY * ao[t]);
+                const T thr = tol2 * (ispo[t] ? T(1) : so[t] * so[t]);
+                const bool pass = hro[t] && !selo[t] && (tno[t] || (valo[t] > thr));
+                mf = num<T>::fma(pass ? T(1) : T(0), bito[t], mf);
+            }
+            int low = (int)qsum<LG>(mf);
+            low = low & (0 - low);
+            // nothing passed (a numerically rank-deficient remainder): the untaken column with the largest projection
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(need1 && (low == 0)) != 0ull, 0)) {
+                T vb = T(-1);
+#pragma unroll
+                for (int t = 0; t < RS; ++t) vb = (hro[t] && !selo[t]) ? num<T>::max(vb, valo[t]) : vb;
+                vb = qmax<LG>(vb);
+                T mb = T(0);
+#pragma unroll
+                for (int t = 0; t < RS; ++t)
+                    mb = num<T>::fma((hro[t] && !selo[t] && (valo[t] == vb)) ? T(1) : T(0), bito[t], mb);
+                int lb = (int)qsum<LG>(mb);
+                lb = lb & (0 - lb);
+                low = (low == 0) ? lb : low;
+            }
+            T fdp = T(0), rsp = T(0);
+#pragma unroll
+            for (int t = 0; t < RS; ++t) {
+                const bool pk = need1 && hro[t] && (low == (int)bito[t]);
+                fdp = pk ? (tno[t] ? T(0) : fdo[t]) : fdp;
+                rsp = pk ? reso[t] : rsp;
+                wto[t] = pk ? tv_last : wto[t];
+                selo[t] = selo[t] || pk;
+            }
+            fds = qsum<LG>(fdp);                               // one lane contributes: exact
+            rs = qsum<LG>(rsp);
+        } else {
+            // (per row on purpose: the column that passes here is typically a LATE one -- the slack of a joint limit, column
+            // 16 of 17 in the iiwa chart (0, 1, 2, 3, 16) -- so a per-lane first-fit scan runs ten trips before it: measured
+            // 4 - 5 us per execution against 1.3 us for testing all eleven columns side by side)
+            T fd[NG], res[NG], val[NG];
+            bool pick[NG];
+            bool any = false;
+            T vbest = T(-1);
+    #pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int r = NF + g;
+                T a = T(0), fu = T(0);
+    #pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    if (E::jac_zero(r, i)) continue;
+                    a = num<T>::fma(A[r][i], beta[i], a);
+                    fu = num<T>::fma(A[r][i], Ua[i], fu);
+                }
+                fd[g] = isp[g] ? beta[NQ] : a;
+                res[g] = isp[g] ? Ua[NQ] - tv_last : num<T>::fma(s[g], tv_last, fu);
+                val[g] = fd[g] * fd[g];
+                const T thr = tol2 * (isp[g] ? T(1) : s[g] * s[g]);
+                const bool pass = !sel[g] && (tiny(g) || (val[g] > thr));
+                pick[g] = need1 && pass && !any;
+                any = any || pass;
+                vbest = sel[g] ? vbest : num<T>::max(vbest, val[g]);
+            }
+            bool taken = false;
+    #pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const bool fb = need1 && !any && !taken && !sel[g] && (val[g] == vbest);
+                pick[g] = pick[g] || fb;
+                taken = taken || fb;
+            }
+            fds = T(0); rs = T(0);
+    #pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                fds = pick[g] ? (tiny(g) ? T(0) : fd[g]) : fds; rs = pick[g] ? res[g] : rs;
+                wtgt[g] = pick[g] ? tv_last : wtgt[g];
+                sel[g] = sel[g] || pick[g];
+            }
         }
         const T coef = (need1 && fds != T(0)) ? num<T>::div(rs, fds) : T(0);
 #pragma unroll
@@ -887,19 +1025,41 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) mu[i] = xa[i] + Ua[i];
+    if constexpr (ROWDIST) {
+        // the slack velocities of the lane's own rows, then one broadcast per row
+        T wo[RS];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int r = NF + g;
-        T wm = y[r], wa = T(0);
+        for (int t = 0; t < RS; ++t) {
+            T wm = yo[t], wa = T(0);
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            if (E::jac_zero(r, i)) continue;
-            wm = num<T>::fma(A[r][i], xa[i], wm);
-            wa = num<T>::fma(A[r][i], Ua[i], wa);
+            for (int i = 0; i < NQ; ++i) {
+                if (slot_zero(t, i)) continue;
+                wm = num<T>::fma(Ao[t][i], xa[i], wm);
+                wa = num<T>::fma(Ao[t][i], Ua[i], wa);
+            }
+            const T inv_s = (hro[t] && (num<T>::abs(so[t]) >= CC::TINY * ao[t])) ? num<T>::rcp(so[t]) : T(0);
+            const T w = selo[t] ? num<T>::fma(-wm, inv_s, wto[t]) : -(wm + wa) * inv_s;
+            wo[t] = ispo[t] ? xa[NQ] + Ua[NQ] : w;
         }
-        const T inv_s = (num<T>::abs(s[g]) >= CC::TINY * arow[g]) ? num<T>::rcp(s[g]) : T(0);
-        const T w = sel[g] ? num<T>::fma(-wm, inv_s, wtgt[g]) : -(wm + wa) * inv_s;
-        mu[NQ + g] = isp[g] ? xa[NQ] + Ua[NQ] : w;
+        static_for<0, NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            mu[NQ + g] = qbcast<g % LG, LG>(wo[g / LG]);
+        });
+    } else {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int r = NF + g;
+            T wm = y[r], wa = T(0);
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                if (E::jac_zero(r, i)) continue;
+                wm = num<T>::fma(A[r][i], xa[i], wm);
+                wa = num<T>::fma(A[r][i], Ua[i], wa);
+            }
+            const T inv_s = (num<T>::abs(s[g]) >= CC::TINY * arow[g]) ? num<T>::rcp(s[g]) : T(0);
+            const T w = sel[g] ? num<T>::fma(-wm, inv_s, wtgt[g]) : -(wm + wa) * inv_s;
+            mu[NQ + g] = isp[g] ? xa[NQ] + Ua[NQ] : w;
+        }
     }
 }
 
