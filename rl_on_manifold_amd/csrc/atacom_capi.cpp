@@ -74,10 +74,12 @@ constexpr int kStatBlocks = 256;
 // Two variants run fewer mappings: the rigid-body kernels (dynamics_mode 1) exist per lane and per quad only -- 8 -> 4,
 // 2 -> 1, and atacom_get_lanes reports what really runs.  The canonical chart (chart_mode 1) distributes the vectors of
 // its square-root recursion over the lanes of a group (atacom_chart.h): the gain per lane added is smaller than with the
-// reference chart's 12 x 17 factorisation, so the groups narrow earlier -- iiwa single steps 4 lanes up to 16384 envs
-// (34.3 vs 36.3 us with one lane at 8192) then one lane (40 us at 32768, 2 lanes 41.6); T-step kernels 8 lanes up to
-// 8192 (21.0 us per step), 4 up to 16384 (22.6), 2 up to 32768 (25.7), one beyond (28.8 at 65536); planar single steps
-// one lane (13.8 vs 14.5 us), its T-step kernels like the reference chart's (profiles/r03_lanes_vs_batch_canonical.log).
+// reference chart's 12 x 17 factorisation, so the groups narrow earlier -- iiwa single steps 8 lanes up to 8192 envs (since
+// the row slots and the static slack stage A of atacom_chart.h: 27.2 us on the bench workload against 29.4 with 4 lanes; 28.5
+// vs 30.0 at 2048, 29.4 vs 30.9 at 4096), 4 lanes up to 16384, then one lane (40 us at 32768, 2 lanes 41.6); T-step kernels
+// 8 lanes up to 8192 (19.7 us per step), 4 up to 16384 (21.5), 2 up to 32768 (25.7), one beyond (28.8 at 65536); planar like
+// the reference chart's kernels (single steps at 8192: 13.8 us with 4 lanes, 14.2 with 2, 15.7 with one;
+// profiles/r03_lanes_vs_batch_canonical.log, r03_ab_rowslots.log, r03_ab_stage_a.log).
 enum { KIND_STEP = 0, KIND_ROLLOUT = 1 };
 int pick_lanes_raw(const atacom_config& c, int kind) {
     if (c.lanes_per_env == 1 || c.lanes_per_env == 2 || c.lanes_per_env == 4 || c.lanes_per_env == 8)
@@ -85,10 +87,10 @@ int pick_lanes_raw(const atacom_config& c, int kind) {
     if (c.dtype == ATACOM_F64) return 1;
     if (c.chart_mode == 1) {
         if (c.env_id == ATACOM_ENV_IIWA) {
-            if (kind == KIND_STEP) return c.batch <= 16384 ? 4 : 1;
+            if (kind == KIND_STEP) return c.batch <= 8192 ? 8 : (c.batch <= 16384 ? 4 : 1);
             return c.batch <= 8192 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));
         }
-        if (c.env_id == ATACOM_ENV_PLANAR && kind == KIND_ROLLOUT)
+        if (c.env_id == ATACOM_ENV_PLANAR)
             return c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1);
         return 1;
     }

@@ -41,6 +41,17 @@ namespace atacom {
 #ifndef ATACOM_CHART_ROWDIST
 #define ATACOM_CHART_ROWDIST 1
 #endif
+// Group kernels, slack stage A (two or more free coordinates missing): the first-fit scan over the slack columns in static row
+// order with a wave-uniform early-out (STATIC_A; compile-time indices, structural zeros, no row gather: 80 instead of 190
+// instructions per candidate), or per lane -- trip n = every environment's n-th untaken column, gathered by one-hot blends.
+// Measured (iiwa, 8192 constraint-active environments, one box, profiles/r03_ab_stage_a.log): static order shortens the
+// SLOWEST wavefronts -- atacom_step 35.7 -> 32.2 us (4 lanes), 35.8 -> 31.0 (8 lanes) -- but lengthens the average one (its
+// eleven unrolled row bodies cost the plain path registers): T-step kernels 19.6 -> 20.4 us per step, the 120-step packed
+// collection 2.14 -> 2.36 ms.  So k_step takes the static form and the T-step kernels keep the per-lane one (0 here: per lane
+// everywhere, for A/B builds).
+#ifndef ATACOM_CHART_STAGEA_STATIC
+#define ATACOM_CHART_STAGEA_STATIC 1
+#endif
 
 template <typename T> struct chart_const {
     static constexpr T THETA = T(3e-2);     // stiff-row threshold (oracle/canonical_chart.py: THETA)
@@ -549,7 +560,7 @@ __device__ __forceinline__ T qmax(T v) {
     }
 }
 
-template <typename T, typename E, int LG>
+template <typename T, typename E, int LG, bool STATIC_A = false>
 __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], const T (&arow)[E::NG], const T (&s)[E::NG],
                                                    const T (&y)[E::NC], const T (&alpha)[E::NK], const T tol, T (&mu)[E::NN],
                                                    const int lq ATACOM_DBG_PARAM) {
@@ -787,45 +798,74 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
 #pragma unroll
             for (int k = 0; k < N1; ++k) wp[k] = qbcast<NQ % LG, LG>(VL[NQ / LG][k]);
             const T fp = qbcast<NQ % LG, LG>(Ul[NQ / LG]);
-            // first fit, per lane group: trip n tests the environment's n-th untaken column (PER-LANE ROWS above)
-            unsigned cand = 0u, pbit = 0u, gsel = 0u;
+            if constexpr (STATIC_A && (ATACOM_CHART_STAGEA_STATIC != 0) && (NG > 6)) {     // (planar, 6 rows: the static form spills)
+                // first fit in STATIC row order with a wave-uniform early-out: row g is looked at while some environment of the
+                // wavefront still has it as a candidate and has not found its column -- as many rows as the slowest
+                // environment scans, but each on compile-time indices (structural zeros, no row gather)
+                static_for<0, NG>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    constexpr int r = NF + g;
+                    const bool act = want && !sel[g] && !any;
+                    if (__builtin_amdgcn_ballot_w64(act) == 0ull) return;
+                    T wa[N1], fa, v = T(0);
+                    functional(StaticRow<T, E, r>{A}, T(0), wa, Ul, fa);                          // f_g = A_g u
+                    T wg[N1];
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                cand |= (want && !sel[g]) ? (1u << g) : 0u;
-                pbit |= isp[g] ? (1u << g) : 0u;
-            }
-#pragma unroll 1
-            while (__builtin_amdgcn_ballot_w64((cand != 0u) && !any) != 0ull) {
-                const bool act = (cand != 0u) && !any;
-                const unsigned low = act ? (cand & (0u - cand)) : 0u;
-                cand ^= low;
-                LaneRow<T, E> row;
-                lane_row<T, E>(A, low, row);
-                const T sg = lane_pick<T, NG>([&](int g) { return s[g]; }, low);
-                const T ag = lane_pick<T, NG>([&](int g) { return arow[g]; }, low);
-                const bool ip = (low & pbit) != 0u;
-                T wa[N1], fa, v = T(0);
-                functional(row, T(0), wa, Ul, fa);                                             // f_g = A_g u
-                T wg[N1];
+                    for (int k = 0; k < N1; ++k) { wg[k] = isp[g] ? wp[k] : wa[k]; v = num<T>::fma(wg[k], wg[k], v); }
+                    const T fu = isp[g] ? fp : fa;
+                    const T thr = tol2 * (isp[g] ? T(1) : s[g] * s[g]);
+                    const bool tn = tiny(g);
+                    const bool take = act && (tn || (v > thr));
 #pragma unroll
-                for (int k = 0; k < N1; ++k) { wg[k] = ip ? wp[k] : wa[k]; v = num<T>::fma(wg[k], wg[k], v); }
-                const T fu = ip ? fp : fa;
-                const T thr = tol2 * (ip ? T(1) : sg * sg);
-                const bool tn = !ip && (num<T>::abs(sg) < CC::TINY * ag);
-                const bool take = act && (tn || (v > thr));
-#pragma unroll
-                for (int k = 0; k < N1; ++k) wsel[k] = take ? wg[k] : wsel[k];
-                vsel = take ? v : vsel;
-                rsel = take ? (ip ? fu - tv : num<T>::fma(sg, tv, fu)) : rsel;
-                tnsel = take ? tn : tnsel;
-                gsel = take ? low : gsel;
-                any = any || take;
-            }
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const bool tk = gsel == (1u << g);
-                wtgt[g] = num<T>::fma(tk ? T(1) : T(0), tv, wtgt[g]);
-                sel[g] = sel[g] || tk;
+                    for (int k = 0; k < N1; ++k) wsel[k] = take ? wg[k] : wsel[k];
+                    vsel = take ? v : vsel;
+                    rsel = take ? (isp[g] ? fu - tv : num<T>::fma(s[g], tv, fu)) : rsel;
+                    tnsel = take ? tn : tnsel;
+                    wtgt[g] = take ? tv : wtgt[g];
+                    sel[g] = sel[g] || take;
+                    any = any || take;
+                });
+            } else {
+                // first fit, per lane group: trip n tests the environment's n-th untaken column (PER-LANE ROWS above)
+                unsigned cand = 0u, pbit = 0u, gsel = 0u;
+    #pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    cand |= (want && !sel[g]) ? (1u << g) : 0u;
+                    pbit |= isp[g] ? (1u << g) : 0u;
+                }
+    #pragma unroll 1
+                while (__builtin_amdgcn_ballot_w64((cand != 0u) && !any) != 0ull) {
+                    const bool act = (cand != 0u) && !any;
+                    const unsigned low = act ? (cand & (0u - cand)) : 0u;
+                    cand ^= low;
+                    LaneRow<T, E> row;
+                    lane_row<T, E>(A, low, row);
+                    const T sg = lane_pick<T, NG>([&](int g) { return s[g]; }, low);
+                    const T ag = lane_pick<T, NG>([&](int g) { return arow[g]; }, low);
+                    const bool ip = (low & pbit) != 0u;
+                    T wa[N1], fa, v = T(0);
+                    functional(row, T(0), wa, Ul, fa);                                             // f_g = A_g u
+                    T wg[N1];
+    #pragma unroll
+                    for (int k = 0; k < N1; ++k) { wg[k] = ip ? wp[k] : wa[k]; v = num<T>::fma(wg[k], wg[k], v); }
+                    const T fu = ip ? fp : fa;
+                    const T thr = tol2 * (ip ? T(1) : sg * sg);
+                    const bool tn = !ip && (num<T>::abs(sg) < CC::TINY * ag);
+                    const bool take = act && (tn || (v > thr));
+    #pragma unroll
+                    for (int k = 0; k < N1; ++k) wsel[k] = take ? wg[k] : wsel[k];
+                    vsel = take ? v : vsel;
+                    rsel = take ? (ip ? fu - tv : num<T>::fma(sg, tv, fu)) : rsel;
+                    tnsel = take ? tn : tnsel;
+                    gsel = take ? low : gsel;
+                    any = any || take;
+                }
+    #pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const bool tk = gsel == (1u << g);
+                    wtgt[g] = num<T>::fma(tk ? T(1) : T(0), tv, wtgt[g]);
+                    sel[g] = sel[g] || tk;
+                }
             }
             done = done || (want && !any);
             const bool live = any && (vsel > T(0)) && !tnsel;

@@ -373,7 +373,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                                // per row carried over the sub-steps instead of two)
     // hoist of the sub-step-invariant first reflector (see prepare): every mapping, ATACOM mode, held q / dq, and an
     // equality row on top of J_c (iiwa; the planar and circle J_c start with a slack-carrying row)
-    constexpr bool CANON = CHART == 1 && E::MODE == 0;
+    constexpr bool CANON = CHART >= 1 && E::MODE == 0;        // CHART 2 (from k_step): canonical, slack stage A in static row order
     constexpr bool G0PRE = HOIST_G0 && HOLD && E::MODE == 0 && NF > 0 && NQ > 1 && !CANON;
     T arow[NG];                 // CANON: max |K J| of every inequality row (the scale its slack is compared with)
     T g0_d = T(0), g0_tau = T(0);
@@ -492,7 +492,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
         }
         if constexpr (CANON) {
             if constexpr (LANES == 1) canonical_mu<T, E>(A, arow, st.s, y, alpha, P.rref_tol, mu ATACOM_DBG_ARG(out.dbg));
-            else canonical_mu_group<T, E, LANES>(A, arow, st.s, y, alpha, P.rref_tol, mu, lq ATACOM_DBG_ARG(out.dbg));
+            else canonical_mu_group<T, E, LANES, CHART == 2>(A, arow, st.s, y, alpha, P.rref_tol, mu, lq ATACOM_DBG_ARG(out.dbg));
         } else if (LANES == 1 || E::MODE != 0) {
             T x[NN], nb[NN][NN - NC], nmu[NN];
             auto aget = [&](auto rc, auto cc) -> T {
@@ -739,7 +739,9 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     unsigned long long ts1;
     asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1) : "v"(st.q[0]) : "memory");
 #endif
-    env_step<T, E, LANES, HOLD, DYN, true, CHART>(P, st, act, out, lq);
+    // single-step launches last as long as their slowest wavefront: the canonical chart's slack stage A runs in static row
+    // order there (atacom_chart.h); the T-step kernels, which average over their steps, keep the per-lane scan
+    env_step<T, E, LANES, HOLD, DYN, true, (CHART == 1 ? 2 : CHART)>(P, st, act, out, lq);
     ATACOM_MARK("STORE");
 #ifdef ATACOM_TIMESTAMPS
     unsigned long long ts2;
