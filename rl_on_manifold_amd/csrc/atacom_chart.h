@@ -828,12 +828,12 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
             } else {
                 // first fit, per lane group: trip n tests the environment's n-th untaken column (PER-LANE ROWS above)
                 unsigned cand = 0u, pbit = 0u, gsel = 0u;
-    #pragma unroll
+#pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     cand |= (want && !sel[g]) ? (1u << g) : 0u;
                     pbit |= isp[g] ? (1u << g) : 0u;
                 }
-    #pragma unroll 1
+#pragma unroll 1
                 while (__builtin_amdgcn_ballot_w64((cand != 0u) && !any) != 0ull) {
                     const bool act = (cand != 0u) && !any;
                     const unsigned low = act ? (cand & (0u - cand)) : 0u;
@@ -846,13 +846,13 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
                     T wa[N1], fa, v = T(0);
                     functional(row, T(0), wa, Ul, fa);                                             // f_g = A_g u
                     T wg[N1];
-    #pragma unroll
+#pragma unroll
                     for (int k = 0; k < N1; ++k) { wg[k] = ip ? wp[k] : wa[k]; v = num<T>::fma(wg[k], wg[k], v); }
                     const T fu = ip ? fp : fa;
                     const T thr = tol2 * (ip ? T(1) : sg * sg);
                     const bool tn = !ip && (num<T>::abs(sg) < CC::TINY * ag);
                     const bool take = act && (tn || (v > thr));
-    #pragma unroll
+#pragma unroll
                     for (int k = 0; k < N1; ++k) wsel[k] = take ? wg[k] : wsel[k];
                     vsel = take ? v : vsel;
                     rsel = take ? (ip ? fu - tv : num<T>::fma(sg, tv, fu)) : rsel;
@@ -860,7 +860,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
                     gsel = take ? low : gsel;
                     any = any || take;
                 }
-    #pragma unroll
+#pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const bool tk = gsel == (1u << g);
                     wtgt[g] = num<T>::fma(tk ? T(1) : T(0), tv, wtgt[g]);
@@ -1005,11 +1005,11 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
             bool pick[NG];
             bool any = false;
             T vbest = T(-1);
-    #pragma unroll
+#pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int r = NF + g;
                 T a = T(0), fu = T(0);
-    #pragma unroll
+#pragma unroll
                 for (int i = 0; i < NQ; ++i) {
                     if (E::jac_zero(r, i)) continue;
                     a = num<T>::fma(A[r][i], beta[i], a);
@@ -1025,14 +1025,14 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
                 vbest = sel[g] ? vbest : num<T>::max(vbest, val[g]);
             }
             bool taken = false;
-    #pragma unroll
+#pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const bool fb = need1 && !any && !taken && !sel[g] && (val[g] == vbest);
                 pick[g] = pick[g] || fb;
                 taken = taken || fb;
             }
             fds = T(0); rs = T(0);
-    #pragma unroll
+#pragma unroll
             for (int g = 0; g < NG; ++g) {
                 fds = pick[g] ? (tiny(g) ? T(0) : fd[g]) : fds; rs = pick[g] ? res[g] : rs;
                 wtgt[g] = pick[g] ? tv_last : wtgt[g];
