@@ -269,3 +269,44 @@ def test_canonical_chart_closed_loop_at_config_4():
     assert np.median(col('canonical', 1)) <= 1.5 * np.median(col('reference', 1)), stats
     m1, d1 = col('canonical', 1).max(), col('canonical', 2).max()
     assert d1 <= 1e-4 and m1 < 0.05
+
+
+@pytest.mark.parametrize('lanes', [1, 2, 4, 8])
+@pytest.mark.parametrize('dt', ['f64', 'f32'])
+@pytest.mark.parametrize('name', ['planar', 'iiwa'])
+def test_canonical_chart_with_refreshed_state_and_exact_bias(name, dt, lanes):
+    """The HOLD = false instantiations of the canonical-chart kernels (hold_q = 0: q, dq and with them A = K J change in
+    every sub-step, so the row-slot copies of the group kernels are rebuilt per sub-step instead of once per step) with
+    bias_mode = exact, against the canonical oracle under the same flags: float64 1e-8 on every sample, float32 close on
+    the bulk (the per-sample float32 rule runs in test_env_step_canonical_chart)."""
+    import dataclasses
+    from oracle import atacom_scalar as osc
+    from rl_on_manifold_amd import BatchedAtacomEnv
+    from test_gpu_parity import _full_state
+    spec = {'planar': osc.planar_spec, 'iiwa': osc.iiwa_spec}[name](bias_mode='exact')
+    spec = dataclasses.replace(spec, chart_mode=1, hold_q=False)
+    B, T = 384, 12
+    env = BatchedAtacomEnv(name, B, device=DEV, dtype=DT[dt], lanes_per_env=lanes, chart_mode='canonical', hold_q=False,
+                           bias_mode='exact')
+    nq = spec.dim_q
+    rng = np.random.default_rng(17)
+    q0 = env.get_state().cpu().numpy().astype(np.float64)[:, :nq] + rng.normal(0, 0.05, (B, nq))
+    o = ob.BatchedAtacomEnv(spec, B, init_q=q0, init_puck=np.array([0.8, 0.4, 0, 0, 0, 0.0]))
+    errs = []
+    for t in range(T):
+        a = rng.uniform(-1.2, 1.2, (B, spec.n_null))
+        env.set_state(_full_state(env, o))
+        obs, r, ab, _ = env.step(a)
+        oo, orr, oab, _ = o.step(a)
+        e = np.maximum(np.abs(obs.double().cpu().numpy() - oo).max(1), np.abs(r.double().cpu().numpy() - orr))
+        errs.append(e)
+    errs = np.concatenate(errs)
+    if dt == 'f64':
+        assert errs.max() < 1e-8, errs.max()
+    else:
+        assert np.median(errs) < 2e-5 and np.quantile(errs, 0.99) < 5e-3, (np.median(errs), np.quantile(errs, 0.99))
+    # and the variant really differs from the held one
+    held = BatchedAtacomEnv(name, B, device=DEV, dtype=DT[dt], lanes_per_env=lanes, chart_mode='canonical')
+    held.set_state(_full_state(held, o)); env.set_state(_full_state(env, o))
+    a = rng.uniform(-1.0, 1.0, (B, spec.n_null))
+    assert (held.step(a)[0] - env.step(a)[0]).abs().max() > 1e-6
