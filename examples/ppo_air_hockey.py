@@ -35,6 +35,7 @@ class Net(nn.Module):                      # same layer names as the reference's
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--env', default='planar')
+    ap.add_argument('--task', default='H', choices=['H', 'D'], help="planar only: 'D' = defending (horizon 180 in the reference)")
     ap.add_argument('--batch', type=int, default=4096)
     ap.add_argument('--iters', type=int, default=60)
     ap.add_argument('--horizon', type=int, default=120)
@@ -44,7 +45,7 @@ def main():
     torch.manual_seed(args.seed)
     dev = torch.device('cuda:0')
     B, T = args.batch, args.horizon
-    env = BatchedAtacomEnv(args.env, B, device=dev, auto_reset=True, horizon=T, random_init=True, seed=args.seed)
+    env = BatchedAtacomEnv(args.env, B, device=dev, auto_reset=True, horizon=T, random_init=True, seed=args.seed, task=args.task)
     D, k = env.obs_dim, env.dims['null']
     # observation normalisation (what MinMaxPreprocessor does with finite bounds): fixed shift / scale
     shift = torch.zeros(D, device=dev)
@@ -100,7 +101,7 @@ def main():
         torch.cuda.synchronize()
         t_fit += time.perf_counter() - t0
         ep_ret = rew.sum(0).mean().item() if not last[:-1].any() else (rew.sum() / last.sum().clamp_min(1)).item()
-        goals = (rew > 70).sum().item()
+        goals = ((rew > 70) if args.task == 'H' else (rew < -40)).sum().item()      # task 'D': goals CONCEDED
         hits = (d['reward'] > 0.99).any(0).float().mean().item()
         print('iter %3d  return/episode %8.3f  goals %5d  frac envs with a hit %.3f  c_max %.4f  c_dq_max %.4f  std %.3f'
               % (it, ep_ret, goals, hits, c_max, c_dq, log_std.exp().mean().item()), flush=True)
