@@ -609,7 +609,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
         return v;
     };
     [[maybe_unused]] T Ao[RS][NQ], so[RS], ao[RS], yo[RS], bito[RS];
-    if constexpr (ROWDIST) {
+    if constexpr (ROWDIST && !STATIC_A) {            // T-step kernels: up front ("WHEN the row slots are built", below)
         T pw = T(0);                                         // 2^lq
 #pragma unroll
         for (int l = 0; l < LG; ++l) pw = num<T>::fma(oh[l], T(1u << l), pw);
@@ -628,6 +628,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
             yo[t] = ownrow([&](int g) { return y[NF + g]; }, t);
             bito[t] = pw * T(1u << (LG * t));                // 2^g of the own row (a lane without a row in the slot never passes)
         }
+    
     }
     // ---- replicated prologue: metric of the soft rows, its Cholesky factor
     bool soft[NG], isp[NG];
@@ -884,7 +885,14 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
     // row slots: the flags of the lane's own rows (stage A, rare, works on the replicated ones)
     [[maybe_unused]] bool ispo[RS], selo[RS], hro[RS];
     [[maybe_unused]] T wto[RS];
-    if constexpr (ROWDIST) {
+    // WHEN the row slots are built.  The blends are not free: built unconditionally they cost a wavefront that stays on the
+    // plain path 1.3 - 2.2 us per step (profiles/r03_phase_probe_3way.log, quiet states: 12.7 -> 15.0 us per wave).  The
+    // single-step kernels (STATIC_A) therefore build them only where some environment of the wavefront needs slack stage B
+    // (wave-uniform), and only then does the assembly take its row-slot form -- a wavefront on the plain path runs the
+    // replicated assembly.  The T-step kernels build them up front: there the blend of A leaves the sub-step loop (A is held
+    // over the sub-steps); built inside the branch it runs four times a step (120-step collection 2.14 vs 2.28 ms).
+    // (Both placements are written out: routed through a shared lambda the arrays went to scratch.)
+    if constexpr (ROWDIST && !STATIC_A) {
 #pragma unroll
         for (int t = 0; t < RS; ++t) {
             ispo[t] = ownflag([&](int g) { return isp[g]; }, t);
@@ -892,7 +900,9 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
             wto[t] = ownrow([&](int g) { return wtgt[g]; }, t);
             hro[t] = (LG * t + LG <= NG) ? true : (lq < NG - LG * t);         // the lane has a row in this slot
         }
+    
     }
+    const bool rowd = ROWDIST && (!STATIC_A || (__builtin_amdgcn_ballot_w64(need1) != 0ull));
     // the coordinates, replicated (needed by stage B and by the assembly)
     T xa[N1], Ua[N1];
     auto gather_all = [&]() {
@@ -904,6 +914,35 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
     };
     if (__builtin_amdgcn_ballot_w64(need1) != 0ull) {
         ATACOM_DBG_COUNT(2);
+        if constexpr (ROWDIST && STATIC_A) {
+            T pw = T(0);                                         // 2^lq
+#pragma unroll
+            for (int l = 0; l < LG; ++l) pw = num<T>::fma(oh[l], T(1u << l), pw);
+#pragma unroll
+            for (int t = 0; t < RS; ++t) {
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    T v = T(0);
+#pragma unroll
+                    for (int l = 0; l < LG; ++l)
+                        if (LG * t + l < NG && !E::jac_zero(NF + LG * t + l, i)) v = num<T>::fma(oh[l], A[NF + LG * t + l][i], v);
+                    Ao[t][i] = v;
+                }
+                so[t] = ownrow([&](int g) { return s[g]; }, t);
+                ao[t] = ownrow([&](int g) { return arow[g]; }, t);
+                yo[t] = ownrow([&](int g) { return y[NF + g]; }, t);
+                bito[t] = pw * T(1u << (LG * t));                // 2^g of the own row (a lane without a row in the slot never passes)
+            }
+    
+#pragma unroll
+            for (int t = 0; t < RS; ++t) {
+                ispo[t] = ownflag([&](int g) { return isp[g]; }, t);
+                selo[t] = ownflag([&](int g) { return sel[g]; }, t);
+                wto[t] = ownrow([&](int g) { return wtgt[g]; }, t);
+                hro[t] = (LG * t + LG <= NG) ? true : (lq < NG - LG * t);         // the lane has a row in this slot
+            }
+    
+        }
         // the longest vector (first maximum in coordinate order, like np.argmax) and who owns it
         T nrm2[N1];
         static_for<0, N1>([&](auto ic) {
@@ -1065,7 +1104,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
     }
 #pragma unroll
     for (int i = 0; i < NQ; ++i) mu[i] = xa[i] + Ua[i];
-    if constexpr (ROWDIST) {
+    if (rowd) {
         // the slack velocities of the lane's own rows, then one broadcast per row
         T wo[RS];
 #pragma unroll
