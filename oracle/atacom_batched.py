@@ -202,8 +202,23 @@ def device_uniform(seed, env, episode, draw):
         x ^= x >> 16
         return x
     key = (np.uint64(seed) + np.asarray(env, dtype=np.uint64) * 0x9E3779B9 + np.asarray(episode, dtype=np.uint64) * 0x85EBCA6B
-           + np.uint64(draw) * 0xC2B2AE35) & 0xffffffff
+           + np.asarray(draw, dtype=np.uint64) * 0xC2B2AE35) & 0xffffffff
     return (h(h(key)) >> 8).astype(np.float64) / 16777216.0
+
+
+OBS_NOISE_STD = 0.001        # env_single.py:105-107
+ENV_NOISE_FORCE = 0.0005     # env_base.py:176-180
+OBS_DELAY_ALPHA = 0.5        # env_single.py:114-117
+
+
+def device_normal(seed, env, episode, t, idx, n_idx):
+    """Standard normal draw number `idx` (of n_idx per env step) of step t of an episode: Box-Muller on two draws of the
+    engine's counter-based generator (atacom_kernels.h: device_normal).  The reference draws from numpy's global, unseeded
+    generator (np.random.randn), so only the distribution can match."""
+    d = 8 + 2 * (np.asarray(t, dtype=np.int64) * n_idx + idx)
+    u1 = device_uniform(seed, env, episode, d)
+    u2 = device_uniform(seed, env, episode, d + 1)
+    return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
 
 
 # ------------------------------------------------------------------ the batched environment
@@ -212,6 +227,12 @@ class BatchedAtacomEnv:
         self.spec, self.B = spec, batch
         self.random_init, self.seed = random_init, seed
         self.episode = np.zeros(batch, dtype=np.int64)
+        self.ep_cur = np.zeros(batch, dtype=np.int64)       # id of the running episode (keys the noise draws)
+        self.noisy = bool(getattr(spec, 'obs_noise', False) or getattr(spec, 'obs_delay', False)
+                          or getattr(spec, 'env_noise', False))
+        if self.noisy and spec.env_id == ENV_CIRCLE:
+            raise ValueError('obs_noise / obs_delay / env_noise exist for the air-hockey environments only')
+        self.n_idx = 3 + 2 * spec.substeps                   # normal draws per env step: 3 (observation) + 2 per sub-step (force)
         nq = spec.dim_q
         if init_q is None:
             init_q = {ENV_CIRCLE: np.array([-1.0, 0.0]), ENV_PLANAR: robots.PLANAR_INIT_Q,
@@ -234,6 +255,8 @@ class BatchedAtacomEnv:
         # row N4 (dynamics_mode = 1): the three servo joints -- joint 7 and the striker's universal joint
         self.qx = np.zeros((batch, 3))
         self.dqx = np.zeros((batch, 3))
+        # obs_delay: the low-pass state obs_prev[3:6] (puck velocity) and obs_prev[robot velocities] of env_single.py:114-119
+        self.fv = np.zeros((batch, 3 + nq))
         self.has_hit = np.zeros(batch, dtype=bool)
         self.has_bounce = np.zeros(batch, dtype=bool)       # task 'D' only
         self.r_hit = np.zeros(batch)
@@ -278,9 +301,16 @@ class BatchedAtacomEnv:
             else:                                           # env_hitting.py:24-25
                 self.puck[m, 0] = -0.6 + 0.4 * u[0]
                 self.puck[m, 1] = -0.4 + 0.8 * u[1]
+            self.ep_cur[m] = ep
+            self.episode[m] += 1
+        elif self.noisy and m.any():
+            self.ep_cur[m] = self.episode[m]                # every reset starts a new episode of the noise streams
             self.episode[m] += 1
         if m.any():
             self.s[m] = self.slack_init(self.q[m], self.dq[m])
+            # the first observation of an episode is unfiltered (the reference's obs_prev is None there -- and its
+            # _create_observation would raise on it; oracle/__init__.py "obs_delay")
+            self.fv[m] = np.concatenate([self.puck[m, 3:6], self.dq[m]], 1)
         return self.observation()
 
     def set_state(self, q, dq, s=None, puck=None):
@@ -294,8 +324,16 @@ class BatchedAtacomEnv:
         if sp.env_id == ENV_CIRCLE:
             return np.concatenate([self.q, self.dq], -1)
         pk = self.puck
-        return np.concatenate([pk[:, 0:1] - sp.base_xy[0], pk[:, 1:2] - sp.base_xy[1], pk[:, 2:6],
-                               self.q, self.dq], -1)
+        pose = np.stack([pk[:, 0] - sp.base_xy[0], pk[:, 1] - sp.base_xy[1], pk[:, 2]], -1)
+        if getattr(sp, 'obs_noise', False):                  # env_single.py:105-107
+            env = np.arange(self.B)
+            pose = pose + OBS_NOISE_STD * np.stack(
+                [device_normal(self.seed, env, self.ep_cur, self.t, c, self.n_idx) for c in range(3)], -1)
+        if getattr(sp, 'obs_delay', False):                  # :114-117 (the filtered values; updated where the reference
+            pv, rv = self.fv[:, :3], self.fv[:, 3:]          # calls _create_observation: see step)
+        else:
+            pv, rv = pk[:, 3:6], self.dq
+        return np.concatenate([pose, pv, self.q, rv], -1)
 
     def tangent_space_accel(self, q, dq, s, alpha, terms=None):
         sp = self.spec
@@ -398,13 +436,20 @@ class BatchedAtacomEnv:
             reward = np.exp(-np.hypot(1.0 - self.q[:, 0], self.q[:, 1]))
             absorbing = np.zeros(self.B, dtype=bool)
         else:
-            q_ctl, dq_ctl = self.q.copy(), self.dq.copy()
+            delay = getattr(sp, 'obs_delay', False)
+            # the wrapper's q, dq are read off the observation the previous step (or the reset) returned
+            # (atacom.py:95-96,111-112): with obs_delay the controller sees the FILTERED joint velocities
+            q_ctl, dq_ctl = self.q.copy(), (self.fv[:, 3:].copy() if delay else self.dq.copy())
             q_sim, dq_sim = self.q.copy(), self.dq.copy()
             terms = constraint_terms(sp, q_ctl, dq_ctl)
             m0 = mallet_xy_world(sp, self.q)
-            for _ in range(sp.substeps):
-                if not sp.hold_q:
-                    q_ctl, dq_ctl = q_sim.copy(), dq_sim.copy()
+            for k in range(sp.substeps):
+                if delay:
+                    # step_action_function calls env._create_observation(sim_state) in every sub-step (atacom.py:124): the
+                    # low-pass advances on the velocities at the START of the sub-step (env_single.py:114-119)
+                    self.fv[:, 3:] = OBS_DELAY_ALPHA * dq_sim + (1 - OBS_DELAY_ALPHA) * self.fv[:, 3:]
+                if not sp.hold_q and k > 0:
+                    q_ctl, dq_ctl = q_sim.copy(), (self.fv[:, 3:].copy() if delay else dq_sim.copy())
                     terms = constraint_terms(sp, q_ctl, dq_ctl)
                 mu = self.tangent_space_accel(q_ctl, dq_ctl, self.s, alpha, terms)
                 self.s = self.s + mu[:, nq:] * sp.dt
@@ -416,14 +461,18 @@ class BatchedAtacomEnv:
             self.q, self.dq = q_sim, dq_sim
             m1 = mallet_xy_world(sp, self.q)
             for k in range(sp.substeps):
-                self._puck_substep(m0 + (m1 - m0) * ((k + 1) / sp.substeps), (m1 - m0) / (sp.substeps * sp.dt))
+                self._puck_substep(m0 + (m1 - m0) * ((k + 1) / sp.substeps), (m1 - m0) / (sp.substeps * sp.dt), k)
             absorbing = self._is_absorbing()
             reward = self._reward(alpha, absorbing)
+            if delay:                                        # the observation the step returns (PyBullet.step [upstream])
+                self.fv = OBS_DELAY_ALPHA * np.concatenate([self.puck[:, 3:6], self.dq], 1) + (1 - OBS_DELAY_ALPHA) * self.fv
             fun, _, _ = constraint_terms(sp, self.q, np.zeros_like(self.q))
             c_i = fun.copy()
             c_i[:, :sp.n_f] = np.abs(c_i[:, :sp.n_f])
             cm = c_i.max(-1)
-            self._log(cm, cm, (np.abs(self.dq) - sp.vel_max).max(-1))
+            # _update_constraint_stats gets the wrapper's dq = the observation's (atacom.py:111-114)
+            dq_seen = self.fv[:, 3:] if delay else self.dq
+            self._log(cm, cm, (np.abs(dq_seen) - sp.vel_max).max(-1))
         self.t += 1
         return self.observation(), reward, absorbing, {}
 
@@ -464,10 +513,18 @@ class BatchedAtacomEnv:
         self.qx = self.qx + self.dqx * sp.dt
         return ddq_a
 
-    def _puck_substep(self, mallet, mallet_vel):
+    def _puck_substep(self, mallet, mallet_vel, k=0):
         """Batched version of atacom_scalar.ScalarAtacomEnv._puck_substep (contact model of this build, row N1)."""
         sp = self.spec
         pk = self.puck
+        if getattr(sp, 'obs_delay', False):                  # the sub-step's _create_observation (see step)
+            self.fv[:, :3] = OBS_DELAY_ALPHA * pk[:, 3:6] + (1 - OBS_DELAY_ALPHA) * self.fv[:, :3]
+        if getattr(sp, 'env_noise', False):
+            # _simulation_pre_step (env_base.py:176-180): force 0.0005 [randn, randn, 0] on the puck for this sub-step
+            env = np.arange(self.B)
+            dv = ENV_NOISE_FORCE * sp.dt / sp.puck_mass
+            for c in range(2):
+                pk[:, 3 + c] += dv * device_normal(self.seed, env, self.ep_cur, self.t, 3 + 2 * k + c, self.n_idx)
         pk[:, 0:3] += pk[:, 3:6] * sp.dt
         d = pk[:, 0:2] - mallet
         dist = np.hypot(d[:, 0], d[:, 1])

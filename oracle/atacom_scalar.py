@@ -65,6 +65,12 @@ class EnvSpec:
                              # AirHockeyDefend [upstream, restated from memory]) -- batched oracle only
     dynamics_mode: int = 0   # 0: inverse o forward dynamics = identity; 1: rigid body (row N4, iiwa,
                              # oracle/dynamics.py -- implemented by the batched oracle only)
+    # domain randomisation of the air-hockey base envs (constructor kwargs of iiwa_hit_atacom.py:11-13 /
+    # atacom_air_hockey.py:12-14, all default False) -- batched oracle only:
+    obs_noise: bool = False  # env_single.py:105-107: puck pose (x, y, yaw) of every observation += N(0, 0.001^2)
+    obs_delay: bool = False  # env_single.py:114-117: puck and joint velocities of every observation low-passed, alpha = 0.5
+    env_noise: bool = False  # env_base.py:176-180: a random planar force 0.0005 N(0, 1) on the puck in every physics sub-step
+    puck_mass: float = 0.01  # kg; MushroomRL's puck.urdf [upstream, from memory -- not in the reference tree]: scales env_noise
 
     @property
     def dt_base(self):

@@ -52,6 +52,12 @@ namespace atacom {
 #ifndef ATACOM_CHART_STAGEA_STATIC
 #define ATACOM_CHART_STAGEA_STATIC 1
 #endif
+// Group kernels: 3 = the third form (atacom_chart_group.h, round 4: own columns, metric by columns, no inverse factor, row
+// slots always, all candidate rows of slack stage A at once); 2 = the second form below (canonical_mu_group), kept for A/B
+// builds (-DATACOM_CHART_FORM=2).
+#ifndef ATACOM_CHART_FORM
+#define ATACOM_CHART_FORM 3
+#endif
 
 template <typename T> struct chart_const {
     static constexpr T THETA = T(3e-2);     // stiff-row threshold (oracle/canonical_chart.py: THETA)
@@ -630,6 +636,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
         }
     
     }
+    ATACOM_MARK("CH_metric");
     // ---- replicated prologue: metric of the soft rows, its Cholesky factor
     bool soft[NG], isp[NG];
     bool has_stiff = false;
@@ -663,6 +670,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
             }
         }
         has_stiff = has_p;
+    ATACOM_MARK("CH_chol");
         T Li[NQ][NQ];
         chol_inverse_factor<T, NQ>(M, Li);
         T z[NQ], x0[NQ];
@@ -680,6 +688,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
             for (int k = i; k < NQ; ++k) a = num<T>::fma(Li[k][i], z[k], a);
             x0[i] = -a;
         }
+    ATACOM_MARK("CH_own");
         const T hp = has_p ? T(1) : T(0);
 #pragma unroll
         for (int sl = 0; sl < S; ++sl) {
@@ -743,6 +752,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
 #pragma unroll
         for (int sl = 0; sl < S; ++sl) xl[sl] = num<T>::fma(g[sl], ce, xl[sl]);
     };
+    ATACOM_MARK("CH_eq");
     if constexpr (NF == 1) condition(StaticRow<T, E, 0>{A}, T(0), T(0), y[0], true);
     if (__builtin_amdgcn_ballot_w64(has_stiff) != 0ull) {
         [[maybe_unused]] const int trips = for_each_stiff_row<T, E>(A, s, y, soft, condition);
@@ -750,6 +760,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
         dbg[0] += trips;
 #endif
     }
+    ATACOM_MARK("CH_joints");
     // ---- the chart: conditioning recursion over the joints with the skip rule
     int n_acc = 0;
     static_for<0, NQ>([&](auto jc) {
@@ -773,6 +784,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
         for (int sl = 0; sl < S; ++sl) Ul[sl] = num<T>::fma(g[sl], coef, Ul[sl]);
         n_acc += acc ? 1 : 0;
     });
+    ATACOM_MARK("CH_stageA");
     // ---- free coordinates still missing after the joints (see canonical_mu)
     // (flags are recomputed where they are cheap: every bool array costs 2 SGPRs per row, and the masks spill)
     bool sel[NG];
@@ -879,6 +891,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
             n_acc += any ? 1 : 0;
         }
     }
+    ATACOM_MARK("CH_stageB");
     // (B) exactly one missing: every v_i = beta_i dhat
     const bool need1 = (n_acc == NK - 1) && !done;
     const T tv_last = alpha[NK - 1];
@@ -1082,6 +1095,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
 #pragma unroll
         for (int sl = 0; sl < S; ++sl) Ul[sl] = num<T>::fma(-bl[sl], coef, Ul[sl]);
     }
+    ATACOM_MARK("CH_asm");
     gather_all();
     // ---- assembly (replicated), as in canonical_mu
     if constexpr (NF == 1) {
@@ -1143,3 +1157,5 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
 }
 
 }  // namespace atacom
+
+#include "atacom_chart_group.h"

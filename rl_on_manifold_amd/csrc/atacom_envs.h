@@ -60,7 +60,16 @@ struct Params {
     T puck_r, mallet_r;        // 0.03165, 0.05 (env_base.py:157-158)
     T e_mallet, e_rim;         // restitution of the contact model of this build
     T term_tol;                // MODE 2: termination tolerance (circle_terminated.py:13)
+    // domain randomisation of the air-hockey base envs (constructor kwargs of iiwa_hit_atacom.py:11-13 /
+    // atacom_air_hockey.py:12-14; all off by default): launch-uniform bits, see NOISE_* below
+    int noise;
+    T obs_noise_std;           // 0.001 (env_single.py:105-107)
+    T env_noise_dv;            // 0.0005 N * dt / puck mass: velocity kick per unit normal draw and sub-step (env_base.py:176-180)
 };
+// Params::noise bits
+constexpr int NOISE_OBS = 1;     // obs_noise: puck pose (x, y, yaw) of every observation += N(0, 0.001^2)   env_single.py:105-107
+constexpr int NOISE_DELAY = 2;   // obs_delay: puck / joint velocities of every observation low-passed, alpha = 0.5   :114-117
+constexpr int NOISE_ENV = 4;     // env_noise: random planar force on the puck in every physics sub-step   env_base.py:176-180
 
 // ---------------------------------------------------------------------------------------- circle
 template <typename T>

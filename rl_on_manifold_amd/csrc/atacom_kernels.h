@@ -48,7 +48,9 @@ struct Planes {
                          SSUM = VHX + 1, SCMAX = SSUM + 1, SDQMAX = SCMAX + 1, HOT = SDQMAX + 1,
                          IQ = HOT, IDQ = IQ + E::NQ, IS = IDQ + E::NQ, IPUCK = IS + E::NG,
                          // row N4 (iiwa): the three servo joints of the rigid-body mode, positions then velocities
-                         QX = IPUCK + 6, DQX = QX + 3, COUNT = (E::ID == 2) ? DQX + 3 : QX;
+                         QX = IPUCK + 6, DQX = QX + 3, AUX_END = (E::ID == 2) ? DQX + 3 : QX,
+                         // obs_delay: the low-pass state of the observation's velocities, puck (3) then joints (NQ)
+                         FV = AUX_END, COUNT = E::PUCK ? FV + 3 + E::NQ : FV;
     static constexpr int HOT_LD = (HOT + 3) / 4 * 4, COLD_LD = (COUNT - HOT + 3) / 4 * 4;
     static constexpr int VALUES_PER_ENV = HOT_LD + COLD_LD;          // allocation: VALUES_PER_ENV * batch elements
     static constexpr int I_HIT = 0, I_T = 1, I_CNT = 2, I_EP = 3, ICOUNT = 4;   // I_EP: episodes started (RNG counter)
@@ -84,6 +86,9 @@ struct EnvState {
     T r_hit, vel_hit_x;
     int has_hit, t;
     T qx[3], dqx[3];            // servo joints (rigid-body mode only; untouched otherwise)
+    // domain randomisation (Params::noise != 0 only; untouched otherwise)
+    T fv[3 + E::NQ];            // obs_delay: filtered puck (3) and joint (NQ) velocities = what the last observation showed
+    int env, ep;                // environment index and id of its running episode: the key of the noise draws
 };
 
 // the servo-joint planes are loaded / stored only by the rigid-body kernels (DYN)
@@ -176,6 +181,20 @@ __device__ __forceinline__ void write_obs(const Params<T>& P, const EnvState<T, 
         o[3] = st.puck[3]; o[4] = st.puck[4]; o[5] = st.puck[5];
 #pragma unroll
         for (int i = 0; i < E::NQ; ++i) { o[6 + i] = st.q[i]; o[6 + E::NQ + i] = st.dq[i]; }
+        if (P.noise & NOISE_OBS) {
+            // env_single.py:105-107; a pure function of (environment, episode, steps taken): the observation of a state is
+            // the same whenever it is produced (step, masked step, reset with an empty mask, the T-step kernels)
+            const int n_idx = 3 + 2 * P.substeps;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                o[c] = num<T>::fma(P.obs_noise_std, device_normal<T>(P.seed, st.env, st.ep, st.t, c, n_idx), o[c]);
+        }
+        if (P.noise & NOISE_DELAY) {                             // :114-117: the filtered values (advanced in env_step)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) o[3 + i] = st.fv[i];
+#pragma unroll
+            for (int i = 0; i < E::NQ; ++i) o[6 + E::NQ + i] = st.fv[3 + i];
+        }
     }
 }
 
@@ -210,6 +229,46 @@ __device__ __forceinline__ T device_uniform(unsigned int seed, int env, int epis
     return (T)(hash_u32(hash_u32(key)) >> 8) * (T)(1.0 / 16777216.0);        // [0, 1) with 24 bits
 }
 
+// Standard normal draw number `idx` (of n_idx per env step) of step t of an episode: Box-Muller on two draws of the
+// counter-based generator above (oracle/atacom_batched.py: device_normal).  The reference draws np.random.randn from the
+// global, unseeded generator, so only the distribution can match.
+template <typename T>
+__device__ __forceinline__ T device_normal(unsigned int seed, int env, int episode, int t, int idx, int n_idx) {
+    const int d = 8 + 2 * (t * n_idx + idx);
+    const T u1 = device_uniform<T>(seed, env, episode, d), u2 = device_uniform<T>(seed, env, episode, d + 1);
+    T sn, cs;
+    num<T>::sincos(T(6.283185307179586) * u2, &sn, &cs);
+    return num<T>::sqrt(T(-2) * num<T>::log(T(1) - u1)) * cs;
+}
+
+// the part of the state only the domain-randomisation options touch (launch-uniform: P.noise)
+template <typename T, typename E>
+__device__ __forceinline__ void load_noise(const Params<T>& P, const T* __restrict__ f, const int* __restrict__ ip, int B,
+                                           int b, EnvState<T, E>& st) {
+    using L = Planes<E>;
+    st.env = b;
+    st.ep = 0;
+    if constexpr (E::PUCK) {
+        if (P.noise) {
+            st.ep = pli(ip, L::I_EP, b) - 1;          // every reset starts a new episode (reset_env): the running one's id
+            if (P.noise & NOISE_DELAY) {
+#pragma unroll
+                for (int i = 0; i < 3 + E::NQ; ++i) st.fv[i] = pl<E>(f, L::FV + i, B, b);
+            }
+        }
+    }
+}
+template <typename T, typename E>
+__device__ __forceinline__ void store_noise(const Params<T>& P, T* __restrict__ f, int B, int b, const EnvState<T, E>& st) {
+    using L = Planes<E>;
+    if constexpr (E::PUCK) {
+        if (P.noise & NOISE_DELAY) {
+#pragma unroll
+            for (int i = 0; i < 3 + E::NQ; ++i) pl<E>(f, L::FV + i, B, b) = st.fv[i];
+        }
+    }
+}
+
 // state <- stored initial state; with P.random_init the random part of the reference's reset is re-drawn and the
 // episode counter advances.  Returns with st.s valid (stored slack, or recomputed when q / dq were randomised).
 template <typename T, typename E>
@@ -217,9 +276,13 @@ __device__ __forceinline__ void reset_env(const Params<T>& P, const T* __restric
                                           int b, EnvState<T, E>& st, bool commit = true) {
     using L = Planes<E>;
     load_init<T, E>(f, B, b, st);
-    if (!P.random_init) return;
+    const bool noisy = E::PUCK && (P.noise != 0);
+    if (!P.random_init && !noisy) return;
     const int ep = pli(ip, L::I_EP, b);
     if (commit) pli(ip, L::I_EP, b) = ep + 1;     // commit = false: a lane shadowing another lane's environment
+    st.env = b;
+    st.ep = ep;                                   // the new episode's id (keys its noise draws)
+    if (P.random_init) {
     if (E::ID == 0) {
         // circle_base.py:36-42
         const T y = T(-0.5) + T(1.5) * device_uniform<T>(P.seed, b, ep, 0);
@@ -248,6 +311,14 @@ __device__ __forceinline__ void reset_env(const Params<T>& P, const T* __restric
         st.puck[0] = T(-0.6) + T(0.4) * device_uniform<T>(P.seed, b, ep, 0);
         st.puck[1] = T(-0.4) + T(0.8) * device_uniform<T>(P.seed, b, ep, 1);
         }
+    }
+    }
+    if constexpr (E::PUCK) {
+        // the first observation of an episode is unfiltered (the reference's obs_prev is None there)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) st.fv[i] = st.puck[3 + i];
+#pragma unroll
+        for (int i = 0; i < E::NQ; ++i) st.fv[3 + i] = st.dq[i];
     }
 }
 
@@ -382,6 +453,9 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
     T Aq[NC][SQ];              // LANES > 1: this lane's columns of [K J | 0] (column c >= 1 -> lane (c-1) % LANES,
                                // slot (c-1) / LANES; column 0 is replicated and read from A directly, atacom_quad.h)
     T tlo[NQ], tup[NQ];         // acc_truncation bounds (atacom.py:117-121): functions of the controller's dq only
+    // CANON, LANES > 1 (third form, atacom_chart_group.h): the lane's own columns / rows of A, built with A
+    constexpr bool CANON3 = CANON && LANES > 1 && (ATACOM_CHART_FORM == 3);
+    [[maybe_unused]] ChartPre<T, E, LGC> cpre;
     auto prepare = [&](int sub) {
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
@@ -450,6 +524,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                     arow[g] = m;
                 }
             }
+            if constexpr (CANON3) chart_prepare<T, E, LGC>(A, arow, yb, P.Kc, lq, cpre);
             ATACOM_MARK("PRE_blend");
             if (LANES > 1 && !CANON) {
                 // this lane's columns of K J: a one-hot blend over the lane group (exact: the mask is 0 / 1 and the
@@ -492,6 +567,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
         }
         if constexpr (CANON) {
             if constexpr (LANES == 1) canonical_mu<T, E>(A, arow, st.s, y, alpha, P.rref_tol, mu ATACOM_DBG_ARG(out.dbg));
+            else if constexpr (CANON3) canonical_mu_group3<T, E, LGC, CHART == 2>(A, cpre, arow, st.s, y, alpha, P.rref_tol, mu, lq ATACOM_DBG_ARG(out.dbg));
             else canonical_mu_group<T, E, LANES, CHART == 2>(A, arow, st.s, y, alpha, P.rref_tol, mu, lq ATACOM_DBG_ARG(out.dbg));
         } else if (LANES == 1 || E::MODE != 0) {
             T x[NN], nb[NN][NN - NC], nmu[NN];

@@ -46,9 +46,12 @@ class BatchedAtacomEnv:
             raise _lib.AtacomError("BatchedAtacomEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
                                    "there is no CPU fallback")
         self.env_id = _ENV_IDS[env] if isinstance(env, str) else int(env)
-        self.device = torch.device(device)
-        if self.device.type != 'cuda':
+        dev = torch.device(device)
+        if dev.type != 'cuda':
             raise _lib.AtacomError("device must be a ROCm GPU ('cuda:N')")
+        # normalised once: torch.device('cuda') != torch.device('cuda:0'), and every comparison below is on self.device
+        self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.device = torch.device('cuda', self._dev_index)
         self.dtype = dtype
         cfg = _lib.default_config(self.env_id)
         cfg.batch = int(batch)
@@ -109,7 +112,6 @@ class BatchedAtacomEnv:
                 cfg.Kc[i] = float(kc[i])
         self.cfg = cfg
         self.batch = int(batch)
-        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         h = C.c_void_p()
         _lib.check(lib.atacom_create(C.byref(cfg), self._dev_index, C.byref(h)))
         self._h = h
@@ -197,7 +199,7 @@ class BatchedAtacomEnv:
                                               self._stream()))
         else:
             m = mask.view(torch.uint8) if (isinstance(mask, torch.Tensor) and mask.dtype == torch.bool
-                                           and mask.device == self.device and mask.is_contiguous()) \
+                                           and self._on_my_device(mask) and mask.is_contiguous()) \
                 else self._as_dev(mask, (B,), torch.uint8)
             if tuple(m.shape) != (B,):
                 raise ValueError("expected a mask of shape (%d,), got %s" % (B, tuple(m.shape)))
@@ -211,11 +213,11 @@ class BatchedAtacomEnv:
         reuses its buffers pays one dict lookup per argument and allocates nothing."""
         if t is None:
             return
-        key = (what, t.data_ptr(), t.dtype, tuple(t.shape))
+        if not isinstance(t, torch.Tensor) or not self._on_my_device(t):
+            raise ValueError("%s must be a torch tensor on %s" % (what, self.device))
+        key = (what, t.data_ptr(), t.dtype, tuple(t.shape), t.stride())
         if key in self._io_ok:
             return
-        if not isinstance(t, torch.Tensor) or t.device != self.device:
-            raise ValueError("%s must be a torch tensor on %s" % (what, self.device))
         if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
             raise ValueError("%s must be a contiguous %s tensor of shape %s (got %s, %s%s)"
                              % (what, dtype, tuple(shape), t.dtype, tuple(t.shape), '' if t.is_contiguous() else ', strided'))
