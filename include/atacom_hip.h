@@ -114,6 +114,24 @@ typedef struct atacom_config {
                                      The reference's CircleEnvAtacom / CircleEnvErrorCorrection hand time_step to the wrapper
                                      only -- slack integration, atacom.py:135 -- while the base CircularMotion keeps its
                                      default 0.01 (circle_atacom.py:7-18, circle_base.py:18-19,62-63): defaults reproduce that */
+    /* Domain randomisation of the air-hockey base environments -- the constructor kwargs of iiwa_hit_atacom.py:11-13 /
+     * atacom_air_hockey.py:12-14, all 0 by default (ATACOM_ENV_PLANAR / _IIWA only).  The reference draws from numpy's global
+     * unseeded generator; here every draw is a counter-based hash of (seed, env, episode, step, draw index), so a run is
+     * reproducible and identical to the oracle's draw for draw. */
+    int32_t obs_noise;            /* 1 = puck pose (x, y, yaw) of every observation += N(0, 0.001^2)   (env_single.py:105-107) */
+    int32_t obs_delay;            /* 1 = puck and joint velocities of every observation are low-passed, alpha = 0.5
+                                     (env_single.py:114-117), advanced at every physics sub-step (step_action_function builds an
+                                     observation per sub-step, atacom.py:124) and once more for the returned observation; the
+                                     wrapper then controls on -- and logs c_dq_max of -- the FILTERED joint velocities
+                                     (atacom.py:95-96,111-114).  As written, the reference's filter raises on an iiwa episode's
+                                     first observation (obs_prev is None) and slices obs_prev[9:12] for six joint velocities:
+                                     what is built is the evident intent -- first observation unfiltered, each velocity
+                                     low-passed with its own previous value */
+    int32_t env_noise;            /* 1 = a random planar force 0.0005 N(0, 1) N on the puck in every physics sub-step
+                                     (env_base.py:176-180), i.e. a velocity kick 0.0005 dt / puck_mass per unit draw */
+    int32_t reserved1;            /* keep 0 */
+    double puck_mass;             /* kg; scales env_noise.  0.01 by default [MushroomRL's puck.urdf, upstream, from memory --
+                                     not in the reference tree] */
 } atacom_config;
 
 typedef struct atacom_handle atacom_handle;
@@ -220,9 +238,12 @@ int atacom_set_state(atacom_handle* h, const void* d_state, void* stream);
 /* Checkpoint / resume of the WHOLE persistent state of a handle -- everything atacom_get_state leaves out as well: the stored
  * initial states, the constraint-statistics accumulators (atacom.py:201-205), the episode counters of the device-side random
  * reset and the servo joints of the rigid-body mode.  An opaque byte image (device memory, caller-owned, at least
- * atacom_snapshot_bytes(h) bytes) valid for a handle created from the same atacom_config; two device-to-device copies on
- * `stream`, no synchronisation.  restore(save(x)) followed by the same calls reproduces the run bit for bit (the reference
- * has no counterpart: its envs are Python objects one would pickle). */
+ * atacom_snapshot_bytes(h) bytes) valid for a handle created from the same atacom_config.  It starts with a 64-byte header
+ * (magic, environment, task, dtype, batch, fields per environment): atacom_snapshot_restore reads it back first -- one
+ * 64-byte device-to-host copy, which synchronises `stream` -- and returns ATACOM_E_INVALID for an image of another handle
+ * shape instead of mis-reading it; save is three device-to-device copies on `stream`, no synchronisation.
+ * restore(save(x)) followed by the same calls reproduces the run bit for bit (the reference has no counterpart: its envs
+ * are Python objects one would pickle). */
 int64_t atacom_snapshot_bytes(const atacom_handle* h);
 int atacom_snapshot_save(atacom_handle* h, void* d_image, void* stream);
 int atacom_snapshot_restore(atacom_handle* h, const void* d_image, void* stream);
@@ -231,6 +252,13 @@ int atacom_snapshot_restore(atacom_handle* h, const void* d_image, void* stream)
  * d_aux [batch, 6] = [q7, qu1, qu2, dq7, dqu1, dqu2].  ATACOM_ENV_IIWA handles only. */
 int atacom_get_aux_state(atacom_handle* h, void* d_aux, void* stream);
 int atacom_set_aux_state(atacom_handle* h, const void* d_aux, void* stream);
+
+/* obs_delay (cfg.obs_delay = 1; planar / iiwa handles): the low-pass state behind the observation's velocities,
+ * d_filter [batch, 3 + dim_q] = [puck vx, vy, yaw rate, joint velocities] as the last observation showed them
+ * (obs_prev[3:6] and the robot-velocity slice of env_single.py:114-119).  Every reset re-initialises it to the unfiltered
+ * velocities; get / set exist for parity injection next to atacom_set_state, and atacom_snapshot_* carries it. */
+int atacom_get_filter_state(atacom_handle* h, void* d_filter, void* stream);
+int atacom_set_filter_state(atacom_handle* h, const void* d_filter, void* stream);
 
 /* Row N4 primitives on n states of the nine movable joints of urdf/iiwa_1.urdf (q, dq, ddq: [n, 9] = joint_1..7,
  * striker_joint_1, striker_joint_2):
@@ -258,6 +286,10 @@ int atacom_forward_dynamics(int32_t dtype, int32_t n, const void* d_q, const voi
  *     d_A [n, c, dim_q] = K J (equality row first), d_s [n, n_g], d_y [n, c] = psi + Kc c, d_alpha [n, k]
  *     -> d_mu [n, dim_q + n_g] = -Jc^+ y + N alpha.  With y = 0 and alpha = e_i it returns column i of the chart's null
  *     basis N (the invariant tests Jc N = 0, Jc mu + y = 0 are built on that). */
+/*   Structural zeros: for the planar / iiwa shapes the entries of d_A that the environment's constraint Jacobian leaves
+ *     structurally zero (joint-limit rows: everything off their diagonal; iiwa row 4, the height of link_4: joints 3..6) are
+ *     NOT READ -- the kernels assemble K J without them -- so a general or perturbed matrix passed here is treated as
+ *     having zeros there. */
 int atacom_canonical_mu(int32_t env_id, int32_t dtype, int32_t n, const void* d_A, const void* d_s, const void* d_y,
                         const void* d_alpha, double tol, void* d_mu, void* stream);
 int atacom_nullspace(int32_t env_id, int32_t dtype, int32_t lanes_per_env /* 1, 2, 4 or 8 */, int32_t n, const void* d_Jc,

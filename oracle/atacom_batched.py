@@ -143,8 +143,11 @@ def bidiag_solve_null(Jc, rhs, k, cond=None):
     return X[:, :, 0], X[:, :, 1:]
 
 
-def rref_tol(N, tol, margin=None, skipped=None):
+def rref_tol(N, tol, margin=None, skipped=None, forced_skip=None):
     """Batched null_space_coordinate.rref(N, row_vectors=False, tol) (lines 40-79).
+    forced_skip (optional bool [B, n]; parity tests only): take the pivot-or-skip decision of column j from forced_skip[:, j]
+    instead of from the tolerance test -- the float64 elimination on SOMEBODY ELSE'S chart decisions (a float32 device's),
+    which separates "the device took the other side of the reference's tolerance test" from arithmetic error.
     margin (optional, [B], updated in place with minimum): how far the DISCRETE decisions of the elimination were from
     `skipped` (optional bool [B], OR-updated): the elimination took the tolerance branch (:56-63) at least once, i.e. the
     result is NOT the reduced echelon basis with the first k coordinates free (and has been zeroed somewhere).
@@ -173,6 +176,8 @@ def rref_tol(N, tol, margin=None, skipped=None):
             mg = np.minimum(np.abs(p - tol), np.where(p > tol, gap, np.inf))
             margin[:] = np.where(active, np.minimum(margin, mg), margin)
         piv = active & (p > tol)
+        if forced_skip is not None:
+            piv = active & ~forced_skip[:, j] & (p > 0)
         skip = active & ~piv
         if skipped is not None:
             skipped |= skip
@@ -228,6 +233,7 @@ class BatchedAtacomEnv:
         self.random_init, self.seed = random_init, seed
         self.episode = np.zeros(batch, dtype=np.int64)
         self.ep_cur = np.zeros(batch, dtype=np.int64)       # id of the running episode (keys the noise draws)
+        self.env_index = np.arange(batch)                   # per-env (survives tests/parity_tools.slice_env): keys the draws
         self.noisy = bool(getattr(spec, 'obs_noise', False) or getattr(spec, 'obs_delay', False)
                           or getattr(spec, 'env_noise', False))
         if self.noisy and spec.env_id == ENV_CIRCLE:
@@ -281,7 +287,7 @@ class BatchedAtacomEnv:
         self.has_bounce[m] = False
         self.qx[m], self.dqx[m] = 0.0, 0.0
         if self.random_init and m.any():
-            env, ep = np.arange(self.B)[m], self.episode[m]
+            env, ep = self.env_index[m], self.episode[m]
             u = [device_uniform(self.seed, env, ep, i) for i in range(5)]
             if self.spec.env_id == ENV_CIRCLE:              # circle_base.py:36-42
                 y = -0.5 + 1.5 * u[0]
@@ -326,7 +332,7 @@ class BatchedAtacomEnv:
         pk = self.puck
         pose = np.stack([pk[:, 0] - sp.base_xy[0], pk[:, 1] - sp.base_xy[1], pk[:, 2]], -1)
         if getattr(sp, 'obs_noise', False):                  # env_single.py:105-107
-            env = np.arange(self.B)
+            env = self.env_index
             pose = pose + OBS_NOISE_STD * np.stack(
                 [device_normal(self.seed, env, self.ep_cur, self.t, c, self.n_idx) for c in range(3)], -1)
         if getattr(sp, 'obs_delay', False):                  # :114-117 (the filtered values; updated where the reference
@@ -372,7 +378,9 @@ class BatchedAtacomEnv:
             x, _ = bidiag_solve_null(Jc, sp.Kc * c, sp.n_null)
             return np.concatenate([alpha, np.zeros((B, ng))], -1) - x
         x, N = bidiag_solve_null(Jc, psi + sp.Kc * c, sp.n_null, getattr(self, 'cond_number', None))
-        Nr = rref_tol(N, sp.rref_tol, getattr(self, 'decision_margin', None), getattr(self, 'chart_skipped', None))
+        follow = getattr(self, 'chart_follow', None)       # parity tests: Jc -> bool [B, n], the decisions to follow
+        Nr = rref_tol(N, sp.rref_tol, getattr(self, 'decision_margin', None), getattr(self, 'chart_skipped', None),
+                      None if follow is None else follow(Jc))
         return -x + np.einsum('bnk,bk->bn', Nr, alpha)
 
     def acc_truncation(self, dq, ddq):
@@ -521,7 +529,7 @@ class BatchedAtacomEnv:
             self.fv[:, :3] = OBS_DELAY_ALPHA * pk[:, 3:6] + (1 - OBS_DELAY_ALPHA) * self.fv[:, :3]
         if getattr(sp, 'env_noise', False):
             # _simulation_pre_step (env_base.py:176-180): force 0.0005 [randn, randn, 0] on the puck for this sub-step
-            env = np.arange(self.B)
+            env = self.env_index
             dv = ENV_NOISE_FORCE * sp.dt / sp.puck_mass
             for c in range(2):
                 pk[:, 3 + c] += dv * device_normal(self.seed, env, self.ep_cur, self.t, 3 + 2 * k + c, self.n_idx)

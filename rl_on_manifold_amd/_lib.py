@@ -17,7 +17,8 @@ MAX_C, MAX_Q = 12, 6
 EXPORTS = ['atacom_snapshot_bytes', 'atacom_snapshot_save', 'atacom_snapshot_restore', 'atacom_rollout_mlp', 'atacom_rollout_packed', 'atacom_get_aux_state', 'atacom_set_aux_state',
            'atacom_inverse_dynamics', 'atacom_forward_dynamics', 'atacom_default_config', 'atacom_get_dims', 'atacom_create', 'atacom_destroy', 'atacom_reset',
            'atacom_step', 'atacom_rollout', 'atacom_get_stats', 'atacom_get_state', 'atacom_set_state',
-           'atacom_nullspace', 'atacom_constraint_terms', 'atacom_step_masked', 'atacom_canonical_mu', 'atacom_last_error', 'atacom_version', 'atacom_get_lanes']
+           'atacom_nullspace', 'atacom_constraint_terms', 'atacom_step_masked', 'atacom_canonical_mu', 'atacom_last_error', 'atacom_version', 'atacom_get_lanes',
+           'atacom_get_filter_state', 'atacom_set_filter_state']
 
 
 class AtacomConfig(C.Structure):
@@ -30,7 +31,9 @@ class AtacomConfig(C.Structure):
                 ('acc_max', C.c_double * MAX_Q), ('Kq', C.c_double * MAX_Q), ('pos_limit', C.c_double * MAX_Q),
                 ('base_xy', C.c_double * 2), ('link', C.c_double * 3), ('term_tol', C.c_double), ('random_init', C.c_int32), ('seed', C.c_int32),
                 ('dynamics_mode', C.c_int32), ('chart_mode', C.c_int32), ('task', C.c_int32), ('reserved0', C.c_int32),
-                ('dt_base', C.c_double)]
+                ('dt_base', C.c_double),
+                ('obs_noise', C.c_int32), ('obs_delay', C.c_int32), ('env_noise', C.c_int32), ('reserved1', C.c_int32),
+                ('puck_mass', C.c_double)]
 
 
 class AtacomMlp(C.Structure):
@@ -95,6 +98,8 @@ def load():
     lib.atacom_snapshot_save.argtypes = [vp, vp, vp]
     lib.atacom_snapshot_restore.argtypes = [vp, vp, vp]
     lib.atacom_set_aux_state.argtypes = [vp, vp, vp]
+    lib.atacom_get_filter_state.argtypes = [vp, vp, vp]
+    lib.atacom_set_filter_state.argtypes = [vp, vp, vp]
     lib.atacom_inverse_dynamics.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp]
     lib.atacom_forward_dynamics.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp, vp]
     lib.atacom_nullspace.argtypes = [i32, i32, i32, i32, vp, vp, C.c_double, vp, vp, vp, vp]

@@ -17,8 +17,9 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + \
     os.environ.get('ATACOM_HIPCC_FLAGS', '').split()
-UNITS = ['atacom_iiwa.hip', 'atacom_iiwa_f64.hip', 'atacom_iiwa_dyn.hip', 'atacom_iiwa_dyn_f64.hip',
-         'atacom_iiwa_dyn_chart.hip', 'atacom_chart_iiwa.hip', 'atacom_planar.hip', 'atacom_chart.hip', 'atacom_circle.hip',
+UNITS = ['atacom_iiwa.hip', 'atacom_iiwa_f64.hip', 'atacom_noise_iiwa.hip', 'atacom_noise_iiwa_f64.hip', 'atacom_iiwa_dyn.hip',
+         'atacom_iiwa_dyn_f64.hip', 'atacom_iiwa_dyn_chart.hip', 'atacom_chart_iiwa.hip', 'atacom_planar.hip',
+         'atacom_noise_planar.hip', 'atacom_chart.hip', 'atacom_circle.hip',
          'atacom_capi.cpp']           # longest first: the pool runs min(cores, units) compilers
 # per-unit extra flags (none at present: -amdgpu-sched-strategy=max-ilp was tried per unit -- planar step kernel -4 %,
 # planar policy-rollout kernel +19 %, iiwa quad kernel +8 % -- and dropped, profiles/r01_lanes_vs_batch.md)

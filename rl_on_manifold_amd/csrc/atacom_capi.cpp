@@ -139,7 +139,27 @@ struct atacom_handle {
     int* ip;        // int fields: [batch][4]
     double* partial_dev;
     double* partial_host;
+    void* snap_dev;       // the header every snapshot image starts with (SnapHeader), device copy
+    void* snap_host;      // pinned: atacom_snapshot_restore reads an image's header into it
 };
+
+// What a snapshot image starts with: enough of the configuration to refuse an image of another handle shape instead of
+// mis-reading it (a different task, environment, dtype, batch or state layout can have the same byte size)
+struct SnapHeader {
+    uint32_t magic, header_bytes;
+    int32_t struct_size, env_id, dtype, batch, n_planes, n_iplanes, task, elem;
+    uint32_t pad[6];
+};
+static_assert(sizeof(SnapHeader) == 64, "snapshot header is 64 bytes");
+constexpr uint32_t kSnapMagic = 0x4e535441u;      // "ATSN"
+static SnapHeader snap_header(const atacom_handle* h) {
+    SnapHeader s;
+    std::memset(&s, 0, sizeof(s));
+    s.magic = kSnapMagic; s.header_bytes = (uint32_t)sizeof(SnapHeader);
+    s.struct_size = h->cfg.struct_size; s.env_id = h->cfg.env_id; s.dtype = h->cfg.dtype; s.batch = h->cfg.batch;
+    s.n_planes = h->ops->n_planes; s.n_iplanes = h->ops->n_iplanes; s.task = h->cfg.task; s.elem = (int32_t)h->ops->elem;
+    return s;
+}
 
 // the stepping entry points of the handle's kernel variant (dynamics_mode x chart_mode)
 struct Stepper {
@@ -151,6 +171,7 @@ static Stepper stepper(const atacom_handle* h) {
     const atacom_config& c = h->cfg;
     const atacom::VariantOps* v = nullptr;
     if (c.dynamics_mode != 0) v = atacom::ops_iiwa_dyn_variant(c.dtype, c.chart_mode);
+    else if (c.obs_noise || c.obs_delay || c.env_noise) v = atacom::ops_noise(c.env_id, c.dtype, c.chart_mode);
     else if (c.chart_mode == 1) v = atacom::ops_chart(c.env_id, c.dtype);
     if (v) return {v->step, v->rollout, v->rollout_mlp};
     return {h->ops->step, h->ops->rollout, h->ops->rollout_mlp};
@@ -204,6 +225,7 @@ int atacom_default_config(int32_t env_id, atacom_config* c) {
     c->term_tol = 0.1;           // circle_terminated.py:13
     c->dynamics_mode = 0;
     c->chart_mode = 0;
+    c->puck_mass = 0.01;
     if (env_id == ATACOM_ENV_CIRCLE || env_id == ATACOM_ENV_CIRCLE_EC || env_id == ATACOM_ENV_CIRCLE_T) {
         // circle_atacom.py:7-18 == circle_error_correction.py:8-21 (same constraints and gains)
         c->substeps = 1; c->horizon = 500; c->dt = 0.01; c->hold_q = 0;
@@ -261,7 +283,14 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
     if (cfg->task != 0 && !(cfg->task == 1 && cfg->env_id == ATACOM_ENV_PLANAR))
         return fail(ATACOM_E_UNSUPPORTED, "atacom_create: task 1 (defend) exists for ATACOM_ENV_PLANAR only "
                                           "(the reference's iiwa wrapper raises NotImplementedError, iiwa_hit_atacom.py:20-21)");
-    if (cfg->reserved0 != 0) return fail(ATACOM_E_INVALID, "atacom_create: reserved0 must be 0");
+    if (cfg->reserved0 != 0 || cfg->reserved1 != 0) return fail(ATACOM_E_INVALID, "atacom_create: reserved fields must be 0");
+    if ((cfg->obs_noise || cfg->obs_delay || cfg->env_noise) && cfg->env_id != ATACOM_ENV_PLANAR && cfg->env_id != ATACOM_ENV_IIWA)
+        return fail(ATACOM_E_UNSUPPORTED, "atacom_create: obs_noise / obs_delay / env_noise exist for the air-hockey "
+                                          "environments only (iiwa_hit_atacom.py:11-13, atacom_air_hockey.py:12-14)");
+    if (cfg->env_noise && !(cfg->puck_mass > 0)) return fail(ATACOM_E_INVALID, "atacom_create: puck_mass must be positive");
+    if ((cfg->obs_noise || cfg->obs_delay || cfg->env_noise) && cfg->dynamics_mode != 0)
+        return fail(ATACOM_E_UNSUPPORTED, "atacom_create: obs_noise / obs_delay / env_noise are compiled for the kinematic mode "
+                                          "(dynamics_mode 0) only");
     if (cfg->chart_mode == 1 && cfg->env_id != ATACOM_ENV_CIRCLE && cfg->env_id != ATACOM_ENV_PLANAR &&
         cfg->env_id != ATACOM_ENV_IIWA)
         return fail(ATACOM_E_INVALID, "atacom_create: chart_mode 1 needs an ATACOM environment (the E / T baselines have no chart)");
@@ -275,6 +304,7 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
     h->device = device;
     h->ops = ops;
     h->f = nullptr; h->ip = nullptr; h->partial_dev = nullptr; h->partial_host = nullptr;
+    h->snap_dev = nullptr; h->snap_host = nullptr;
     const size_t B = (size_t)cfg->batch;
     void* drow = nullptr;
     // default initial state for every env, then a full reset
@@ -291,6 +321,12 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
     if (e == hipSuccess) e = hipMalloc((void**)&h->partial_dev, sizeof(double) * 4 * kStatBlocks);
     if (e == hipSuccess) e = hipHostMalloc((void**)&h->partial_host, sizeof(double) * 4 * kStatBlocks);
     if (e == hipSuccess) e = hipMalloc(&drow, bytes.size());
+    if (e == hipSuccess) e = hipMalloc(&h->snap_dev, sizeof(SnapHeader));
+    if (e == hipSuccess) e = hipHostMalloc(&h->snap_host, sizeof(SnapHeader));
+    if (e == hipSuccess) {
+        const SnapHeader sh = snap_header(h);
+        e = hipMemcpy(h->snap_dev, &sh, sizeof(sh), hipMemcpyHostToDevice);
+    }
     if (e == hipSuccess) {
         what = "initialisation";
         e = hipMemset(h->f, 0, ops->elem * ops->n_planes * B);
@@ -320,6 +356,8 @@ int atacom_destroy(atacom_handle* h) {
     if (h->ip) (void)hipFree(h->ip);
     if (h->partial_dev) (void)hipFree(h->partial_dev);
     if (h->partial_host) (void)hipHostFree(h->partial_host);
+    if (h->snap_dev) (void)hipFree(h->snap_dev);
+    if (h->snap_host) (void)hipHostFree(h->snap_host);
     delete h;
     return ATACOM_OK;
 }
@@ -460,21 +498,23 @@ int atacom_set_state(atacom_handle* h, const void* d_state, void* stream) {
     return ATACOM_OK;
 }
 
-// ---- checkpoint / resume: the image is [float fields | int fields] exactly as the handle holds them
+// ---- checkpoint / resume: the image is [header (64 bytes) | float fields | int fields] exactly as the handle holds them
 static size_t snapshot_float_bytes(const atacom_handle* h) {
     const size_t raw = (size_t)h->ops->elem * h->ops->n_planes * (size_t)h->cfg.batch;
     return (raw + 15) & ~(size_t)15;
 }
 int64_t atacom_snapshot_bytes(const atacom_handle* h) {
     if (!h) { fail(ATACOM_E_INVALID, "atacom_snapshot_bytes: null handle"); return ATACOM_E_INVALID; }
-    return (int64_t)(snapshot_float_bytes(h) + sizeof(int) * h->ops->n_iplanes * (size_t)h->cfg.batch);
+    return (int64_t)(sizeof(SnapHeader) + snapshot_float_bytes(h) + sizeof(int) * h->ops->n_iplanes * (size_t)h->cfg.batch);
 }
 int atacom_snapshot_save(atacom_handle* h, void* d_image, void* stream) {
     if (!h || !d_image) return fail(ATACOM_E_INVALID, "atacom_snapshot_save: null argument");
     ON_DEVICE(h);
     const size_t B = (size_t)h->cfg.batch, nf = (size_t)h->ops->elem * h->ops->n_planes * B;
-    HIP_TRY(hipMemcpyAsync(d_image, h->f, nf, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    HIP_TRY(hipMemcpyAsync((char*)d_image + snapshot_float_bytes(h), h->ip, sizeof(int) * h->ops->n_iplanes * B,
+    char* img = (char*)d_image;
+    HIP_TRY(hipMemcpyAsync(img, h->snap_dev, sizeof(SnapHeader), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(img + sizeof(SnapHeader), h->f, nf, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(img + sizeof(SnapHeader) + snapshot_float_bytes(h), h->ip, sizeof(int) * h->ops->n_iplanes * B,
                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return ATACOM_OK;
 }
@@ -482,8 +522,23 @@ int atacom_snapshot_restore(atacom_handle* h, const void* d_image, void* stream)
     if (!h || !d_image) return fail(ATACOM_E_INVALID, "atacom_snapshot_restore: null argument");
     ON_DEVICE(h);
     const size_t B = (size_t)h->cfg.batch, nf = (size_t)h->ops->elem * h->ops->n_planes * B;
-    HIP_TRY(hipMemcpyAsync(h->f, d_image, nf, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    HIP_TRY(hipMemcpyAsync(h->ip, (const char*)d_image + snapshot_float_bytes(h), sizeof(int) * h->ops->n_iplanes * B,
+    const char* img = (const char*)d_image;
+    // the header comes to the host first (64 bytes; synchronises `stream`): an image of another handle shape is refused
+    HIP_TRY(hipMemcpyAsync(h->snap_host, img, sizeof(SnapHeader), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    const SnapHeader want = snap_header(h);
+    if (std::memcmp(h->snap_host, &want, sizeof(SnapHeader)) != 0) {
+        const SnapHeader* got = (const SnapHeader*)h->snap_host;
+        if (got->magic != kSnapMagic) return fail(ATACOM_E_INVALID, "atacom_snapshot_restore: not a snapshot image (bad magic)");
+        char msg[256];
+        std::snprintf(msg, sizeof(msg), "atacom_snapshot_restore: the image belongs to another handle shape (env %d dtype %d batch %d "
+                      "task %d, %d + %d fields per env; this handle: env %d dtype %d batch %d task %d, %d + %d)", got->env_id, got->dtype,
+                      got->batch, got->task, got->n_planes, got->n_iplanes, want.env_id, want.dtype, want.batch, want.task,
+                      want.n_planes, want.n_iplanes);
+        return fail(ATACOM_E_INVALID, msg);
+    }
+    HIP_TRY(hipMemcpyAsync(h->f, img + sizeof(SnapHeader), nf, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipMemcpyAsync(h->ip, img + sizeof(SnapHeader) + snapshot_float_bytes(h), sizeof(int) * h->ops->n_iplanes * B,
                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return ATACOM_OK;
 }
@@ -504,6 +559,22 @@ int atacom_set_aux_state(atacom_handle* h, const void* d_aux, void* stream) {
     atacom::ops_iiwa_dyn(h->cfg.dtype)->set_aux(h->cfg, h->f, d_aux, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
+}
+
+static int filter_io(atacom_handle* h, void* d_buf, int set, void* stream, const char* who) {
+    if (!h || !d_buf) return fail(ATACOM_E_INVALID, std::string(who) + ": null argument");
+    if (h->cfg.env_id != ATACOM_ENV_PLANAR && h->cfg.env_id != ATACOM_ENV_IIWA)
+        return fail(ATACOM_E_INVALID, std::string(who) + ": ATACOM_ENV_PLANAR / ATACOM_ENV_IIWA only");
+    ON_DEVICE(h);
+    h->ops->filter_io(h->cfg, h->f, d_buf, set, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return ATACOM_OK;
+}
+int atacom_get_filter_state(atacom_handle* h, void* d_filter, void* stream) {
+    return filter_io(h, d_filter, 0, stream, "atacom_get_filter_state");
+}
+int atacom_set_filter_state(atacom_handle* h, const void* d_filter, void* stream) {
+    return filter_io(h, const_cast<void*>(d_filter), 1, stream, "atacom_set_filter_state");
 }
 
 int atacom_inverse_dynamics(int32_t dtype, int32_t n, const void* d_q, const void* d_dq, const void* d_ddq, void* d_tau,

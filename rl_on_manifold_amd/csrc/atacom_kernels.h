@@ -86,9 +86,25 @@ struct EnvState {
     T r_hit, vel_hit_x;
     int has_hit, t;
     T qx[3], dqx[3];            // servo joints (rigid-body mode only; untouched otherwise)
-    // domain randomisation (Params::noise != 0 only; untouched otherwise)
-    T fv[3 + E::NQ];            // obs_delay: filtered puck (3) and joint (NQ) velocities = what the last observation showed
-    int env, ep;                // environment index and id of its running episode: the key of the noise draws
+};
+
+// Where an environment's persistent state lives: handed to the pieces of a step that only the domain-randomisation
+// options (Params::noise, off by default) touch.  NOISE is a COMPILE-TIME switch of the stepping kernels: the handles that
+// ask for obs_noise / obs_delay / env_noise run their own instantiations (atacom_noise_*.hip), everybody else runs kernels
+// that do not contain the options at all.  (First built as launch-uniform branches of the one kernel set, with the
+// options' state kept out of the registers: the untaken branches still cost 2-4 % per step -- iiwa quad 28.1 -> 29.1 us,
+// 8 lanes 26.1 -> 27.0, planar 11.0 -> 11.4 on one box, profiles/r04_ab_noise_options.log -- through the register
+// allocation of kernels that run at the edge of the register file.)  Inside the NOISE kernels the options' state -- the
+// low-pass of obs_delay (planes FV), the id of the running episode that keys the draws (I_EP - 1) -- is read from /
+// written to the state buffer where it is needed instead of being carried across the solver; a thread only ever re-reads
+// what it wrote itself (every lane of a group stores the same bits), which needs no fence.
+template <typename T, bool NOISE>
+struct EnvRef {
+    static constexpr bool noise = NOISE;
+    T* f;
+    int* ip;
+    int B, b;
+    bool commit;                // false: a lane shadowing another lane's environment (k_rollout_mlp) -- no stores
 };
 
 // the servo-joint planes are loaded / stored only by the rigid-body kernels (DYN)
@@ -172,48 +188,6 @@ __device__ __forceinline__ void load_init(const T* __restrict__ f, int B, int b,
     for (int i = 0; i < 3; ++i) st.qx[i] = st.dqx[i] = T(0);      // the servo set-points vanish at the reset pose
 }
 
-template <typename T, typename E>
-__device__ __forceinline__ void write_obs(const Params<T>& P, const EnvState<T, E>& st, T* __restrict__ o) {
-    if (E::ID == 0) {                                           // circle_base.py:83-84
-        o[0] = st.q[0]; o[1] = st.q[1]; o[2] = st.dq[0]; o[3] = st.dq[1];
-    } else {                                                    // env_single.py:82-120
-        o[0] = st.puck[0] - P.base_x; o[1] = st.puck[1] - P.base_y; o[2] = st.puck[2];
-        o[3] = st.puck[3]; o[4] = st.puck[4]; o[5] = st.puck[5];
-#pragma unroll
-        for (int i = 0; i < E::NQ; ++i) { o[6 + i] = st.q[i]; o[6 + E::NQ + i] = st.dq[i]; }
-        if (P.noise & NOISE_OBS) {
-            // env_single.py:105-107; a pure function of (environment, episode, steps taken): the observation of a state is
-            // the same whenever it is produced (step, masked step, reset with an empty mask, the T-step kernels)
-            const int n_idx = 3 + 2 * P.substeps;
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                o[c] = num<T>::fma(P.obs_noise_std, device_normal<T>(P.seed, st.env, st.ep, st.t, c, n_idx), o[c]);
-        }
-        if (P.noise & NOISE_DELAY) {                             // :114-117: the filtered values (advanced in env_step)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) o[3 + i] = st.fv[i];
-#pragma unroll
-            for (int i = 0; i < E::NQ; ++i) o[6 + E::NQ + i] = st.fv[3 + i];
-        }
-    }
-}
-
-// slack initialisation, atacom.py:145-149
-template <typename T, typename E>
-__device__ __forceinline__ void slack_init(const Params<T>& P, EnvState<T, E>& st) {
-    T fun[E::NC], J[E::NC][E::NQ], bst[E::NC];
-    constraint_terms(E{}, P, st.q, st.dq, fun, J, bst);
-#pragma unroll
-    for (int g = 0; g < E::NG; ++g) {
-        const int r = E::NF + g;
-        T jdq = T(0);
-#pragma unroll
-        for (int i = 0; i < E::NQ; ++i) jdq = num<T>::fma(J[r][i], st.dq[i], jdq);
-        const T gv = num<T>::fma(P.K[r], jdq, fun[r]);
-        st.s[g] = num<T>::sqrt(num<T>::max(T(-2) * gv, T(0)));
-    }
-}
-
 // ---- random initialisation on the device (A16, the random_init branches of circle_base.py:36-42 and
 // env_hitting.py:24-25).  The reference draws from numpy's global, unseeded generator, so only the distribution can
 // be matched; here the draws are a counter-based hash of (seed, env index, episode index, draw index), i.e. stateless,
@@ -241,48 +215,66 @@ __device__ __forceinline__ T device_normal(unsigned int seed, int env, int episo
     return num<T>::sqrt(T(-2) * num<T>::log(T(1) - u1)) * cs;
 }
 
-// the part of the state only the domain-randomisation options touch (launch-uniform: P.noise)
-template <typename T, typename E>
-__device__ __forceinline__ void load_noise(const Params<T>& P, const T* __restrict__ f, const int* __restrict__ ip, int B,
-                                           int b, EnvState<T, E>& st) {
-    using L = Planes<E>;
-    st.env = b;
-    st.ep = 0;
-    if constexpr (E::PUCK) {
-        if (P.noise) {
-            st.ep = pli(ip, L::I_EP, b) - 1;          // every reset starts a new episode (reset_env): the running one's id
-            if (P.noise & NOISE_DELAY) {
+template <typename T, typename E, typename Ref>
+__device__ __forceinline__ void write_obs(const Params<T>& P, const EnvState<T, E>& st, T* __restrict__ o,
+                                          const Ref& ref) {
+    if (E::ID == 0) {                                           // circle_base.py:83-84
+        o[0] = st.q[0]; o[1] = st.q[1]; o[2] = st.dq[0]; o[3] = st.dq[1];
+    } else {                                                    // env_single.py:82-120
+        o[0] = st.puck[0] - P.base_x; o[1] = st.puck[1] - P.base_y; o[2] = st.puck[2];
+        o[3] = st.puck[3]; o[4] = st.puck[4]; o[5] = st.puck[5];
 #pragma unroll
-                for (int i = 0; i < 3 + E::NQ; ++i) st.fv[i] = pl<E>(f, L::FV + i, B, b);
+        for (int i = 0; i < E::NQ; ++i) { o[6 + i] = st.q[i]; o[6 + E::NQ + i] = st.dq[i]; }
+        if constexpr (E::PUCK && Ref::noise) {
+            using L = Planes<E>;
+            if (P.noise & NOISE_OBS) {
+                // env_single.py:105-107; a pure function of (environment, episode, steps taken): the observation of a state is
+                // the same whenever it is produced (step, masked step, reset with an empty mask, the T-step kernels)
+                const int n_idx = 3 + 2 * P.substeps;
+                const int ep = pli(ref.ip, L::I_EP, ref.b) - 1;      // every reset starts an episode: the running one's id
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    o[c] = num<T>::fma(P.obs_noise_std, device_normal<T>(P.seed, ref.b, ep, st.t, c, n_idx), o[c]);
+            }
+            if (P.noise & NOISE_DELAY) {                         // :114-117: the filtered values (advanced in env_step)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) o[3 + i] = pl<E>(ref.f, L::FV + i, ref.B, ref.b);
+#pragma unroll
+                for (int i = 0; i < E::NQ; ++i) o[6 + E::NQ + i] = pl<E>(ref.f, L::FV + 3 + i, ref.B, ref.b);
             }
         }
     }
 }
+
+// slack initialisation, atacom.py:145-149
 template <typename T, typename E>
-__device__ __forceinline__ void store_noise(const Params<T>& P, T* __restrict__ f, int B, int b, const EnvState<T, E>& st) {
-    using L = Planes<E>;
-    if constexpr (E::PUCK) {
-        if (P.noise & NOISE_DELAY) {
+__device__ __forceinline__ void slack_init(const Params<T>& P, EnvState<T, E>& st) {
+    T fun[E::NC], J[E::NC][E::NQ], bst[E::NC];
+    constraint_terms(E{}, P, st.q, st.dq, fun, J, bst);
 #pragma unroll
-            for (int i = 0; i < 3 + E::NQ; ++i) pl<E>(f, L::FV + i, B, b) = st.fv[i];
-        }
+    for (int g = 0; g < E::NG; ++g) {
+        const int r = E::NF + g;
+        T jdq = T(0);
+#pragma unroll
+        for (int i = 0; i < E::NQ; ++i) jdq = num<T>::fma(J[r][i], st.dq[i], jdq);
+        const T gv = num<T>::fma(P.K[r], jdq, fun[r]);
+        st.s[g] = num<T>::sqrt(num<T>::max(T(-2) * gv, T(0)));
     }
 }
 
-// state <- stored initial state; with P.random_init the random part of the reference's reset is re-drawn and the
-// episode counter advances.  Returns with st.s valid (stored slack, or recomputed when q / dq were randomised).
-template <typename T, typename E>
-__device__ __forceinline__ void reset_env(const Params<T>& P, const T* __restrict__ f, int* __restrict__ ip, int B,
-                                          int b, EnvState<T, E>& st, bool commit = true) {
+// state <- stored initial state; with P.random_init (and `draw`) the random part of the reference's reset is re-drawn.
+// The episode counter advances whenever something is keyed by it (random_init, the noise options).  Returns with st.s
+// valid (stored slack, or recomputed when q / dq were randomised).
+template <typename T, typename E, typename Ref>
+__device__ __forceinline__ void reset_env(const Params<T>& P, const Ref& ref, EnvState<T, E>& st, bool draw = true) {
     using L = Planes<E>;
-    load_init<T, E>(f, B, b, st);
-    const bool noisy = E::PUCK && (P.noise != 0);
+    const int B = ref.B, b = ref.b;
+    load_init<T, E>(ref.f, B, b, st);
+    const bool noisy = E::PUCK && Ref::noise && (P.noise != 0);
     if (!P.random_init && !noisy) return;
-    const int ep = pli(ip, L::I_EP, b);
-    if (commit) pli(ip, L::I_EP, b) = ep + 1;     // commit = false: a lane shadowing another lane's environment
-    st.env = b;
-    st.ep = ep;                                   // the new episode's id (keys its noise draws)
-    if (P.random_init) {
+    const int ep = pli(ref.ip, L::I_EP, b);
+    if (ref.commit) pli(ref.ip, L::I_EP, b) = ep + 1;
+    if (P.random_init && draw) {
     if (E::ID == 0) {
         // circle_base.py:36-42
         const T y = T(-0.5) + T(1.5) * device_uniform<T>(P.seed, b, ep, 0);
@@ -313,12 +305,14 @@ __device__ __forceinline__ void reset_env(const Params<T>& P, const T* __restric
         }
     }
     }
-    if constexpr (E::PUCK) {
-        // the first observation of an episode is unfiltered (the reference's obs_prev is None there)
+    if constexpr (E::PUCK && Ref::noise) {
+        if ((P.noise & NOISE_DELAY) && ref.commit) {
+            // the first observation of an episode is unfiltered (the reference's obs_prev is None there)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) st.fv[i] = st.puck[3 + i];
+            for (int i = 0; i < 3; ++i) pl<E>(ref.f, L::FV + i, B, b) = st.puck[3 + i];
 #pragma unroll
-        for (int i = 0; i < E::NQ; ++i) st.fv[3 + i] = st.dq[i];
+            for (int i = 0; i < E::NQ; ++i) pl<E>(ref.f, L::FV + 3 + i, B, b) = st.dq[i];
+        }
     }
 }
 
@@ -400,9 +394,10 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
 // (and bitwise identically) by the four lanes; `lq` is the lane's index in its quad.
 // CHART = 1: the opt-in canonical chart (atacom_chart.h) instead of the reference's LAPACK-basis + rref(tol) chart; with
 // LANES > 1 its square-root recursion is distributed over the lanes of the group (one vector per lane with 8 lanes).
-template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, bool HOIST_G0 = true, int CHART = 0>
+template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, bool HOIST_G0 = true, int CHART = 0, typename Ref>
 __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st, const T (&act)[E::NK],
-                                         StepOut<T>& out, const int lq) {
+                                         StepOut<T>& out, const int lq, const Ref& ref) {
+    using L = Planes<E>;
     constexpr int NQ = E::NQ, NF = E::NF, NG = E::NG, NC = E::NC, NN = E::NN, NK = E::NK;
     T alpha[NK];
     T anorm2 = T(0);
@@ -458,8 +453,17 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
     [[maybe_unused]] ChartPre<T, E, LGC> cpre;
     auto prepare = [&](int sub) {
 #pragma unroll
+            for (int i = 0; i < NQ; ++i) { qc[i] = st.q[i]; dqc[i] = st.dq[i]; }
+            if constexpr (E::PUCK && Ref::noise) {
+                if (P.noise & NOISE_DELAY) {
+                    // obs_delay: the wrapper's dq is read off the observation (atacom.py:95-96,111-112) -- the FILTERED joint
+                    // velocities (as the last observation showed them; advanced per sub-step below)
+#pragma unroll
+                    for (int i = 0; i < NQ; ++i) dqc[i] = pl<E>(ref.f, L::FV + 3 + i, ref.B, ref.b);
+                }
+            }
+#pragma unroll
             for (int i = 0; i < NQ; ++i) {
-                qc[i] = st.q[i]; dqc[i] = st.dq[i];
                 // lo <= up always (K_q, vel_max > 0 and both are clamped into [-acc_max, acc_max])
                 tup[i] = num<T>::max(num<T>::min(P.acc_max[i], -P.Kq[i] * (dqc[i] - P.vel_max[i])), -P.acc_max[i]);
                 tlo[i] = num<T>::min(num<T>::max(-P.acc_max[i], -P.Kq[i] * (dqc[i] + P.vel_max[i])), P.acc_max[i]);
@@ -553,6 +557,19 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
     for (int sub = 0; sub < P.substeps; ++sub) {
         // HOLD (the reference's zero-order hold of q, dq -- quirk Q1) is a template parameter so that the ~1.4 k
         // instructions of the kinematics stay out of the sub-step loop in the default configuration (measured -3.5 %)
+        if constexpr (E::PUCK && Ref::noise) {
+            if (P.noise & NOISE_DELAY) {
+                // step_action_function calls env._create_observation(sim_state) in every sub-step (atacom.py:124): the
+                // low-pass advances on the velocities at the START of the sub-step (env_single.py:114-119).  Through the
+                // state buffer, not a register (EnvRef)
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    const T fo = pl<E>(ref.f, L::FV + 3 + i, ref.B, ref.b);
+                    const T fn = num<T>::fma(T(0.5), st.dq[i], T(0.5) * fo);
+                    if (ref.commit) pl<E>(ref.f, L::FV + 3 + i, ref.B, ref.b) = fn;
+                }
+            }
+        }
         if constexpr (!HOLD || E::MODE == 1) {
             if (sub > 0) prepare(sub);
         }
@@ -665,10 +682,36 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
             const T ux = (mxy[0] - m0x) * inv_n / P.dt, uy = (mxy[1] - m0y) * inv_n / P.dt;
             const T R = P.puck_r + P.mallet_r;
             const T ylim = P.table_hy - P.puck_r, xlim = P.table_hx - P.puck_r;
+            // domain randomisation (NOISE kernels only)
+            const bool delay = E::PUCK && Ref::noise && (P.noise & NOISE_DELAY) != 0;
+            const bool kick = E::PUCK && Ref::noise && (P.noise & NOISE_ENV) != 0;
+            T fvp[3] = {T(0), T(0), T(0)};
+            int ep_run = 0;
+            if constexpr (E::PUCK && Ref::noise) {
+                if (delay) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) fvp[i] = pl<E>(ref.f, L::FV + i, ref.B, ref.b);
+                }
+                if (kick) ep_run = pli(ref.ip, L::I_EP, ref.b) - 1;
+            }
 #pragma unroll 1
             for (int k = 0; k < P.substeps; ++k) {
                 const T fr = (T)(k + 1) * inv_n;
                 const T mx = num<T>::fma(mxy[0] - m0x, fr, m0x), my = num<T>::fma(mxy[1] - m0y, fr, m0y);
+                if constexpr (E::PUCK && Ref::noise) {
+                    if (delay) {                 // the sub-step's _create_observation (env_single.py:114-116)
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) fvp[i] = num<T>::fma(T(0.5), st.puck[3 + i], T(0.5) * fvp[i]);
+                    }
+                    if (kick) {                  // _simulation_pre_step, env_base.py:176-180: force 0.0005 [randn, randn, 0]
+                        const int n_idx = 3 + 2 * P.substeps;
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+                            st.puck[3 + c] = num<T>::fma(P.env_noise_dv,
+                                                         device_normal<T>(P.seed, ref.b, ep_run, st.t, 3 + 2 * k + c, n_idx),
+                                                         st.puck[3 + c]);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < 3; ++i) st.puck[i] = num<T>::fma(st.puck[3 + i], P.dt, st.puck[i]);
                 const T dxm = st.puck[0] - mx, dym = st.puck[1] - my;
@@ -709,6 +752,15 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                     const bool new_hit = (st.has_hit == 0) && (pv2k > T(0.01));      // env_hitting.py:80-85
                     st.vel_hit_x = new_hit ? st.puck[3] : st.vel_hit_x;
                     st.has_hit = new_hit ? 1 : st.has_hit;
+                }
+            }
+            if constexpr (E::PUCK && Ref::noise) {
+                if (delay) {                     // the puck part of the observation the step returns (see the joints' below)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const T fn = num<T>::fma(T(0.5), st.puck[3 + i], T(0.5) * fvp[i]);
+                        if (ref.commit) pl<E>(ref.f, L::FV + i, ref.B, ref.b) = fn;
+                    }
                 }
             }
         }
@@ -762,6 +814,20 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
         T dm = num<T>::abs(st.dq[0]) - P.vel_max[0];
 #pragma unroll
         for (int i = 1; i < NQ; ++i) dm = num<T>::max(dm, num<T>::abs(st.dq[i]) - P.vel_max[i]);
+        if constexpr (E::PUCK && Ref::noise) {
+            if (P.noise & NOISE_DELAY) {
+                // the observation the step returns advances the low-pass once more (env_single.py:114-119; the puck's part
+                // was stored right after its sub-steps), and _update_constraint_stats gets the wrapper's dq = the observation's (atacom.py:111-114)
+#pragma unroll
+                for (int i = 0; i < NQ; ++i) {
+                    const T fo = pl<E>(ref.f, L::FV + 3 + i, ref.B, ref.b);
+                    const T fn = num<T>::fma(T(0.5), st.dq[i], T(0.5) * fo);
+                    if (ref.commit) pl<E>(ref.f, L::FV + 3 + i, ref.B, ref.b) = fn;
+                    const T d = num<T>::abs(fn) - P.vel_max[i];
+                    dm = (i == 0) ? d : num<T>::max(dm, d);
+                }
+            }
+        }
         out.log_avg = out.log_max = cm;
         out.log_dq = dm;
     }
@@ -772,7 +838,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
 // ------------------------------------------------------------------ kernels
 // mask (nullable): environments whose byte is 0 sit the call out -- state, step counter and statistics untouched; they
 // report their current observation, reward 0, absorbing 0, last 0 (a vectorised Core's finished environments).
-template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, int CHART = 0>
+template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, int CHART = 0, bool NOISE = false>
 __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __restrict__ f, int* __restrict__ ip,
                                                const T* __restrict__ action, T* __restrict__ obs,
                                                T* __restrict__ reward, uint8_t* __restrict__ absorbing,
@@ -786,6 +852,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     const int b = gt / LANES;                  // whole quads leave together (BLOCK % LANES == 0)
     const int lq = gt % LANES;
     if (b >= B) return;
+    const EnvRef<T, NOISE> ref{f, ip, B, b, true};
 #ifdef ATACOM_TIMESTAMPS        // tuning build only (tests/gpu_phase_probe.py): 100 MHz wall-clock stamps per phase
     const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -793,7 +860,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     load_state<T, E>(f, ip, B, b, st);
     if (mask && mask[b] == 0) {                // whole lane groups leave together (the mask is per environment)
         if (lq == 0) {
-            write_obs<T, E>(P, st, obs + (size_t)b * E::OBS);
+            write_obs<T, E>(P, st, obs + (size_t)b * E::OBS, ref);
             reward[b] = T(0);
             absorbing[b] = 0;
             if (last) last[b] = 0;
@@ -817,14 +884,14 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
 #endif
     // single-step launches last as long as their slowest wavefront: the canonical chart's slack stage A runs in static row
     // order there (atacom_chart.h); the T-step kernels, which average over their steps, keep the per-lane scan
-    env_step<T, E, LANES, HOLD, DYN, true, (CHART == 1 ? 2 : CHART)>(P, st, act, out, lq);
+    env_step<T, E, LANES, HOLD, DYN, true, (CHART == 1 ? 2 : CHART)>(P, st, act, out, lq, ref);
     ATACOM_MARK("STORE");
 #ifdef ATACOM_TIMESTAMPS
     unsigned long long ts2;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts2) : "v"(out.reward) : "memory");
 #endif
     if (lq != 0) return;                       // the four lanes hold identical results; lane 0 writes
-    write_obs<T, E>(P, st, obs + (size_t)b * E::OBS);
+    write_obs<T, E>(P, st, obs + (size_t)b * E::OBS, ref);
     reward[b] = out.reward;
     absorbing[b] = out.absorbing ? 1 : 0;
     if (last) last[b] = out.last ? 1 : 0;
@@ -832,7 +899,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     pl<E>(f, L::SCMAX, B, b) = num<T>::max(scmax0, out.log_max);
     pl<E>(f, L::SDQMAX, B, b) = num<T>::max(sdq0, out.log_dq);
     pli(ip, L::I_CNT, b) = cnt0 + 1;
-    if (P.auto_reset && out.last) reset_env<T, E>(P, f, ip, B, b, st);
+    if (P.auto_reset && out.last) reset_env<T, E>(P, ref, st);
     store_state<T, E>(f, ip, B, b, st);
     if constexpr (DYN) store_aux<T, E>(f, B, b, st);
 #ifdef ATACOM_TIMESTAMPS
@@ -846,7 +913,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
 #endif
 }
 
-template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, int CHART = 0>
+template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, int CHART = 0, bool NOISE = false>
 __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int n_steps, T* __restrict__ f,
                                                   int* __restrict__ ip, const T* __restrict__ actions,
                                                   T* __restrict__ obs, T* __restrict__ next_obs,
@@ -859,6 +926,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
     const int b = gt / LANES;
     const int lq = gt % LANES;
     if (b >= B) return;
+    const EnvRef<T, NOISE> ref{f, ip, B, b, true};
     EnvState<T, E> st;
     load_state<T, E>(f, ip, B, b, st);
     if constexpr (DYN) load_aux<T, E>(f, B, b, st);
@@ -882,23 +950,23 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
         }
         if (lq == 0) {
             if (rec) {
-                write_obs<T, E>(P, st, rrow + R::OBS);
+                write_obs<T, E>(P, st, rrow + R::OBS, ref);
 #pragma unroll
                 for (int k = 0; k < E::NK; ++k) rrow[R::ACT + k] = act[k];
             } else {
-                write_obs<T, E>(P, st, obs + row * E::OBS);
+                write_obs<T, E>(P, st, obs + row * E::OBS, ref);
             }
         }
         StepOut<T> out;
-        env_step<T, E, LANES, HOLD, DYN, true, CHART>(P, st, act, out, lq);
+        env_step<T, E, LANES, HOLD, DYN, true, CHART>(P, st, act, out, lq, ref);
         if (lq == 0) {
             if (rec) {
-                write_obs<T, E>(P, st, rrow + R::NOBS);
+                write_obs<T, E>(P, st, rrow + R::NOBS, ref);
                 rrow[R::REW] = out.reward;
                 rrow[R::ABS] = out.absorbing ? T(1) : T(0);
                 rrow[R::LAST] = out.last ? T(1) : T(0);
             } else {
-                if (next_obs) write_obs<T, E>(P, st, next_obs + row * E::OBS);
+                if (next_obs) write_obs<T, E>(P, st, next_obs + row * E::OBS, ref);
                 reward[row] = out.reward;
                 absorbing[row] = out.absorbing ? 1 : 0;
                 last[row] = out.last ? 1 : 0;
@@ -907,7 +975,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
         ssum += out.log_avg;
         scmax = num<T>::max(scmax, out.log_max);
         sdq = num<T>::max(sdq, out.log_dq);
-        if (P.auto_reset && out.last) reset_env<T, E>(P, f, ip, B, b, st);
+        if (P.auto_reset && out.last) reset_env<T, E>(P, ref, st);
     }
     if (lq != 0) return;
     pl<E>(f, L::SSUM, B, b) += ssum;
@@ -937,7 +1005,7 @@ struct MlpPath {
     static constexpr int STAGE = (THREADS / WAVE) * LM::wave_stage(NB);   // floats of per-wave staging per workgroup
 };
 
-template <typename T, typename E, int LANES, bool HOLD, int H, bool DYN = false, int CHART = 0>
+template <typename T, typename E, int LANES, bool HOLD, int H, bool DYN = false, int CHART = 0, bool NOISE = false>
 __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const MlpArgs<T> net, int n_steps,
                                                       T* __restrict__ f, int* __restrict__ ip,
                                                       const T* __restrict__ noise, T* __restrict__ obs,
@@ -968,6 +1036,7 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
     constexpr int NB = MlpPath<T, E, LANES, H>::NB;
     T* stage = lds + 2 * LM::NET + (threadIdx.x / WAVE) * LM::wave_stage(NB);  // MFMA path only
     const int erow = lane / LANES;                                             // own environment within the wavefront
+    const EnvRef<T, NOISE> ref{f, ip, B, b, valid};
     EnvState<T, E> st;
     load_state<T, E>(f, ip, B, b, st);
     if constexpr (DYN) load_aux<T, E>(f, B, b, st);
@@ -981,7 +1050,7 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
 #pragma unroll
         for (int k = 0; k < E::NK; ++k) eps[k] = noise ? noise[row * E::NK + k] : T(0);
         T o[E::OBS];
-        write_obs<T, E>(P, st, o);
+        write_obs<T, E>(P, st, o, ref);
         T act[E::NK], sig[E::NK];
         if constexpr (MFMA) {
             float xin[NB][LM::CH];
@@ -1021,15 +1090,15 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
         // (one environment per lane with the network's four GEMM blocks live is the one kernel at the edge of the register
         // file: with the G(0) hoist its spills move INTO the sub-step loop -- 59.6 -> 79.5 us per step, measured -- so it
         // keeps the un-hoisted solver)
-        env_step<T, E, LANES, HOLD, DYN, (LANES > 1), CHART>(P, st, act, out, lq);
+        env_step<T, E, LANES, HOLD, DYN, (LANES > 1), CHART>(P, st, act, out, lq, ref);
         if (lq == 0 && valid) {
             if (rec) {
-                write_obs<T, E>(P, st, rrow + R::NOBS);
+                write_obs<T, E>(P, st, rrow + R::NOBS, ref);
                 rrow[R::REW] = out.reward;
                 rrow[R::ABS] = out.absorbing ? T(1) : T(0);
                 rrow[R::LAST] = out.last ? T(1) : T(0);
             } else {
-                if (next_obs) write_obs<T, E>(P, st, next_obs + row * E::OBS);
+                if (next_obs) write_obs<T, E>(P, st, next_obs + row * E::OBS, ref);
                 reward[row] = out.reward;
                 absorbing[row] = out.absorbing ? 1 : 0;
                 last[row] = out.last ? 1 : 0;
@@ -1038,7 +1107,7 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
         ssum += out.log_avg;
         scmax = num<T>::max(scmax, out.log_max);
         sdq = num<T>::max(sdq, out.log_dq);
-        if (P.auto_reset && out.last) reset_env<T, E>(P, f, ip, B, b, st, valid);
+        if (P.auto_reset && out.last) reset_env<T, E>(P, ref, st);
     }
     if (lq != 0 || !valid) return;
     pl<E>(f, L::SSUM, B, b) += ssum;
@@ -1058,6 +1127,7 @@ __global__ void __launch_bounds__(WAVE) k_reset(const Params<T> P, T* __restrict
     const int b = blockIdx.x * WAVE + threadIdx.x;
     if (b >= B) return;
     const bool m = mask ? (mask[b] != 0) : true;
+    const EnvRef<T, E::PUCK> ref{f, ip, B, b, true};      // the reset kernel carries the options as run-time branches
     EnvState<T, E> st;
     if (m) {
         if (init) {
@@ -1076,13 +1146,14 @@ __global__ void __launch_bounds__(WAVE) k_reset(const Params<T> P, T* __restrict
         slack_init<T, E>(P, st);                 // slack of the STORED initial state (reused by every auto-reset)
 #pragma unroll
         for (int g = 0; g < E::NG; ++g) pl<E>(f, L::IS + g, B, b) = st.s[g];
-        if (P.random_init && !init) reset_env<T, E>(P, f, ip, B, b, st);     // an explicit state wins over the draw
+        // an explicit state wins over the draw; every reset starts a new episode of the noise streams
+        if ((P.random_init && !init) || (E::PUCK && P.noise != 0)) reset_env<T, E>(P, ref, st, !init);
         store_state<T, E>(f, ip, B, b, st);
         if constexpr (E::ID == 2) store_aux<T, E>(f, B, b, st);              // servo joints back to rest
     } else {
         load_state<T, E>(f, ip, B, b, st);
     }
-    if (obs) write_obs<T, E>(P, st, obs + (size_t)b * E::OBS);
+    if (obs) write_obs<T, E>(P, st, obs + (size_t)b * E::OBS, ref);
 }
 
 // set the stored initial state of every env to one row (used by create), clear statistics
@@ -1184,6 +1255,21 @@ __global__ void k_set_state(int B, T* __restrict__ f, int* __restrict__ ip, cons
     st.has_hit = ((int)o[k++]) & 3;                 // bit 0 has_hit, bit 1 has_bounce (task 'D')
     st.r_hit = o[k++]; st.vel_hit_x = o[k++]; st.t = (int)o[k++];
     store_state<T, E>(f, ip, B, b, st);
+}
+
+// obs_delay: the low-pass state of the observation's velocities <-> [B, 3 + NQ] = [puck vx, vy, yaw rate, dq]
+template <typename T, typename E>
+__global__ void k_filter_io(int B, T* __restrict__ f, T* __restrict__ buf, int set) {
+    using L = Planes<E>;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if constexpr (E::PUCK) {
+#pragma unroll
+        for (int i = 0; i < 3 + E::NQ; ++i) {
+            if (set) pl<E>(f, L::FV + i, B, b) = buf[(size_t)b * (3 + E::NQ) + i];
+            else buf[(size_t)b * (3 + E::NQ) + i] = pl<E>(f, L::FV + i, B, b);
+        }
+    }
 }
 
 // servo-joint state <-> [B, 6] = [q7, qu1, qu2, dq7, dqu1, dqu2]  (iiwa)

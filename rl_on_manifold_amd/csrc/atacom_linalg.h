@@ -48,6 +48,7 @@ template <> struct num<float> {
     static __device__ __forceinline__ float copysign(float m, float s) { return __builtin_copysignf(m, s); }
     static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
     static __device__ __forceinline__ float exp(float x) { return expf(x); }
+    static __device__ __forceinline__ float log(float x) { return logf(x); }
     // tanh(x) = sign(x) (1 - 2 / (exp(2|x|) + 1)) on v_exp_f32 / v_rcp_f32: branch-free, |err| < 3e-7 (libm's tanhf
     // inlines ~100 instructions with divergent range branches -- per hidden unit)
     static __device__ __forceinline__ float tanh(float x) {
@@ -94,6 +95,7 @@ template <> struct num<double> {
     static __device__ __forceinline__ double copysign(double m, double s) { return __builtin_copysign(m, s); }
     static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
     static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
+    static __device__ __forceinline__ double log(double x) { return ::log(x); }
     static __device__ __forceinline__ double tanh(double x) { return ::tanh(x); }
     static __device__ __forceinline__ void sincos(double x, double* s, double* c) { ::sincos(x, s, c); }
     static __device__ __forceinline__ double acos(double x) { return ::acos(x); }

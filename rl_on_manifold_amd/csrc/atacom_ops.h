@@ -32,6 +32,8 @@ struct EnvOps {
                       hipStream_t s);
     void (*terms)(const atacom_config&, int n, const void* q, const void* dq, void* fun, void* J, void* b,
                   hipStream_t s);
+    // obs_delay: the low-pass state [batch, 3 + nq] (planar / iiwa; no-op otherwise); set != 0 writes it
+    void (*filter_io)(const atacom_config&, void* f, void* buf, int set, hipStream_t s);
 };
 
 // The three stepping entry points of a kernel variant other than the default one (atacom_ops_impl.h: Variant)
@@ -49,6 +51,9 @@ struct VariantOps {
 };
 // canonical-chart kernels (cfg.chart_mode = 1) of circle / planar / iiwa: atacom_chart.hip, atacom_chart_iiwa.hip
 const VariantOps* ops_chart(int env_id, int dtype);
+// the stepping kernels with the domain-randomisation options (cfg.obs_noise / obs_delay / env_noise) compiled in: planar and
+// iiwa, kinematic mode, either chart (atacom_noise_planar.hip, atacom_noise_iiwa.hip, atacom_noise_iiwa_f64.hip)
+const VariantOps* ops_noise(int env_id, int dtype, int chart_mode);
 // Row N4: the rigid-body kernels of the iiwa environment (cfg.dynamics_mode = 1) with either chart: atacom_iiwa_dyn.hip
 const VariantOps* ops_iiwa_dyn_variant(int dtype, int chart_mode);
 

@@ -31,6 +31,9 @@ static Params<T> make_params(const atacom_config& c) {
     P.ee_height = (T)0.1505; P.z4_min = (T)0.36; P.z7_min = (T)0.25;
     P.puck_r = (T)0.03165; P.mallet_r = (T)mallet_r; P.e_mallet = (T)0.8; P.e_rim = (T)0.8;
     P.term_tol = (T)c.term_tol;
+    P.noise = (c.obs_noise ? NOISE_OBS : 0) | (c.obs_delay ? NOISE_DELAY : 0) | (c.env_noise ? NOISE_ENV : 0);
+    P.obs_noise_std = (T)0.001;                                               // env_single.py:105-107
+    P.env_noise_dv = (T)(0.0005 * c.dt / (c.puck_mass > 0 ? c.puck_mass : 0.01));   // env_base.py:176-180
     return P;
 }
 
@@ -40,8 +43,10 @@ static inline int nblk(int n, int per) { return (n + per - 1) / per; }
 // N4), the reference's chart or the canonical one (CHART, atacom_chart.h).  Mappings: LANES in {1, 2, 4, 8}, x HOLD; the
 // rigid-body kernels exist for one environment per lane and per quad (the dynamics are computed redundantly by the lanes of
 // a group: wider groups buy nothing), atacom_capi.cpp clamps the mapping accordingly.
-template <typename T, typename E, bool DYN, int CHART>
+// NOISE: the kernels with the domain-randomisation options compiled in (planar / iiwa, kinematic mode; atacom_noise_*.hip).
+template <typename T, typename E, bool DYN, int CHART, bool NOISE = false>
 struct Variant {
+    static_assert(!NOISE || (E::PUCK && !DYN), "noise kernels: air-hockey environments, kinematic mode");
     static constexpr bool WIDE = !DYN;                 // lanes 2 and 8 instantiated
     template <typename F>
     static void with_mapping(int lanes, bool hold, F&& f) {
@@ -61,7 +66,7 @@ struct Variant {
         with_mapping(lanes, c.hold_q != 0, [&](auto lc, auto hc) {
             constexpr int LANES = decltype(lc)::value;
             constexpr bool HOLD = decltype(hc)::value;
-            hipLaunchKernelGGL((k_step<T, E, LANES, HOLD, DYN, CHART>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)),
+            hipLaunchKernelGGL((k_step<T, E, LANES, HOLD, DYN, CHART, NOISE>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)),
                                dim3(BLOCK<LANES>), 0, s, make_params<T>(c), (T*)f, ip, (const T*)act, (T*)obs, (T*)rew, ab,
                                last, mask);
         });
@@ -71,7 +76,7 @@ struct Variant {
         with_mapping(lanes, c.hold_q != 0, [&](auto lc, auto hc) {
             constexpr int LANES = decltype(lc)::value;
             constexpr bool HOLD = decltype(hc)::value;
-            hipLaunchKernelGGL((k_rollout<T, E, LANES, HOLD, DYN, CHART>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)),
+            hipLaunchKernelGGL((k_rollout<T, E, LANES, HOLD, DYN, CHART, NOISE>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)),
                                dim3(BLOCK<LANES>), 0, s, make_params<T>(c), n_steps, (T*)f, ip, (const T*)acts, (T*)obs,
                                (T*)nobs, (T*)rew, ab, last, (T*)rec, rec_ld);
         });
@@ -88,7 +93,7 @@ struct Variant {
         }
         const size_t lds_bytes = sizeof(T) * (((lds_floats + 3) / 4) * 4);
         constexpr int THREADS = MlpPath<T, E, LANES, H>::THREADS;
-        hipLaunchKernelGGL((k_rollout_mlp<T, E, LANES, HOLD, H, DYN, CHART>), dim3(nblk(c.batch * LANES, THREADS)),
+        hipLaunchKernelGGL((k_rollout_mlp<T, E, LANES, HOLD, H, DYN, CHART, NOISE>), dim3(nblk(c.batch * LANES, THREADS)),
                            dim3(THREADS), lds_bytes, s, make_params<T>(c), a, n_steps, (T*)f, ip, (const T*)noise, (T*)obs,
                            (T*)nobs, (T*)acts, (T*)rew, ab, last, (T*)rec, rec_ld);
     }
@@ -133,7 +138,7 @@ struct Variant {
     }
     static void chart_mu(int n, const void* A, const void* sl, const void* y, const void* alpha, double tol, void* mu,
                          hipStream_t s) {
-        if constexpr (E::MODE == 0 && !DYN)
+        if constexpr (E::MODE == 0 && !DYN && !NOISE)
             hipLaunchKernelGGL((k_chart<T, E>), dim3(nblk(n, WAVE)), dim3(WAVE), 0, s, n, (const T*)A, (const T*)sl,
                                (const T*)y, (const T*)alpha, (T)tol, (T*)mu);
     }
@@ -191,10 +196,13 @@ struct Ops {
         hipLaunchKernelGGL((k_terms<T, E>), dim3(nblk(n, WAVE)), dim3(WAVE), 0, s, make_params<T>(c), n,
                            (const T*)q, (const T*)dq, (T*)fun, (T*)J, (T*)b);
     }
+    static void filter_io(const atacom_config& c, void* f, void* buf, int set, hipStream_t s) {
+        hipLaunchKernelGGL((k_filter_io<T, E>), dim3(nblk(c.batch, 256)), dim3(256), 0, s, c.batch, (T*)f, (T*)buf, set);
+    }
     static const EnvOps* table() {
         static const EnvOps ops = {L::VALUES_PER_ENV, L::ICOUNT, L::STATE_DIM, L::INIT_DIM, E::OBS, E::NQ, E::NF, E::NG, E::NK,
                                    sizeof(T), &V::step, &V::rollout, &V::rollout_mlp, &reset, &fill_init, &clear_stats, &stats,
-                                   &get_state, &set_state, &nullspace, &terms};
+                                   &get_state, &set_state, &nullspace, &terms, &filter_io};
         return &ops;
     }
 };

@@ -40,7 +40,8 @@ class BatchedAtacomEnv:
     def __init__(self, env, batch, device='cuda:0', dtype=torch.float32, horizon=None, gamma=None, Kc=None,
                  time_step=None, n_intermediate_steps=None, action_penalty=None, auto_reset=False,
                  hold_q=None, bias_mode='reference', rref_tol=None, lanes_per_env=0, term_tol=None, random_init=False, seed=0,
-                 dynamics_mode='kinematic', chart_mode='reference', task='H'):
+                 dynamics_mode='kinematic', chart_mode='reference', task='H', obs_noise=False, obs_delay=False,
+                 env_noise=False, puck_mass=None):
         lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.AtacomError("BatchedAtacomEnv needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -100,6 +101,12 @@ class BatchedAtacomEnv:
         if task == 'D' and self.env_id != _lib.ENV_PLANAR:
             raise NotImplementedError("task 'D' exists for the planar environment only (iiwa_hit_atacom.py:20-21 raises too)")
         cfg.task = tasks[task]
+        # domain randomisation of the air-hockey base envs (iiwa_hit_atacom.py:11-13, atacom_air_hockey.py:12-14): noise on
+        # the observed puck pose, a low-pass on the observed velocities, a random force on the puck -- drawn on the device
+        # from the counter-based generator keyed by `seed` (include/atacom_hip.h)
+        cfg.obs_noise, cfg.obs_delay, cfg.env_noise = int(bool(obs_noise)), int(bool(obs_delay)), int(bool(env_noise))
+        if puck_mass is not None:
+            cfg.puck_mass = float(puck_mass)
         d = _lib.get_dims(self.env_id)
         self.dims = {'q': d.dim_q, 'f': d.n_f, 'g': d.n_g, 'null': d.n_null, 'c': d.n_f + d.n_g}   # atacom.py:25-40
         self.obs_dim, self.state_dim, self.init_state_dim = d.obs_dim, d.state_dim, d.init_state_dim
@@ -282,7 +289,8 @@ class BatchedAtacomEnv:
         records [T, batch_stride, record_dim] = [obs | action | reward | next_obs | absorbing | last] -- the layout the
         sharded collector all-gathers as it is (rollout.py).  Either `actions` [T, B, k] or `policy` (an MlpPolicy,
         evaluated inside the kernel; `noise` [T, B, k] or None) with `n_steps`.  batch_stride > batch pads the env axis
-        (ragged shards); the padding rows are zero-filled once at allocation and never written."""
+        (ragged shards); the padding rows are zero (filled at allocation, or here when the caller supplies `out`) and never
+        written by the kernel."""
         B, k, F = self.batch, self.dims['null'], self.record_dim
         if (actions is None) == (policy is None):
             raise ValueError("give either actions or policy")
@@ -291,8 +299,11 @@ class BatchedAtacomEnv:
         if out is None:
             alloc = torch.empty if ld == B else torch.zeros
             out = alloc((T, ld, F), device=self.device, dtype=self.dtype)
-        elif tuple(out.shape) != (T, ld, F) or not out.is_contiguous() or out.dtype != self.dtype:
-            raise ValueError("out must be a contiguous [%d, %d, %d] tensor of the engine's dtype" % (T, ld, F))
+        elif tuple(out.shape) != (T, ld, F) or not out.is_contiguous() or out.dtype != self.dtype \
+                or not self._on_my_device(out):
+            raise ValueError("out must be a contiguous [%d, %d, %d] tensor of the engine's dtype on %s" % (T, ld, F, self.device))
+        elif ld > B:
+            out[:, B:].zero_()                  # a caller's buffer may hold anything: the padding rows are zero (rollout.py)
         if actions is not None:
             a = self._as_dev(actions, (T, B, k))
             _lib.check(self._lib.atacom_rollout_packed(self._h, T, _ptr(a), None, None, _ptr(out), ld, self._stream()))
@@ -344,10 +355,13 @@ class BatchedAtacomEnv:
         return out
 
     def restore(self, image):
+        """Reads the image's 64-byte header back first (synchronises the current stream) and raises ValueError for an
+        image taken from another handle shape (environment, task, dtype, batch)."""
         n = int(self._lib.atacom_snapshot_bytes(self._h))
         if image.dtype != torch.uint8 or image.numel() < n or not self._on_my_device(image) or not image.is_contiguous():
             raise ValueError("snapshot image must be a contiguous uint8 tensor of >= %d bytes on %s" % (n, self.device))
-        _lib.check(self._lib.atacom_snapshot_restore(self._h, _ptr(image), self._stream()))
+        if self._lib.atacom_snapshot_restore(self._h, _ptr(image), self._stream()) != 0:
+            raise ValueError(self._lib.atacom_last_error().decode())
 
     def get_constraints_logs(self, clear=True):
         res = (C.c_double * 3)()
@@ -374,6 +388,16 @@ class BatchedAtacomEnv:
     def set_aux_state(self, aux):
         a = self._as_dev(aux, (self.batch, 6))
         _lib.check(self._lib.atacom_set_aux_state(self._h, _ptr(a), self._stream()))
+
+    def get_filter_state(self):
+        """obs_delay: the low-pass state behind the observed velocities, [B, 3 + dim_q] = [puck vx, vy, yaw rate, dq]."""
+        fv = torch.empty((self.batch, 3 + self.dims['q']), device=self.device, dtype=self.dtype)
+        _lib.check(self._lib.atacom_get_filter_state(self._h, _ptr(fv), self._stream()))
+        return fv
+
+    def set_filter_state(self, fv):
+        a = self._as_dev(fv, (self.batch, 3 + self.dims['q']))
+        _lib.check(self._lib.atacom_set_filter_state(self._h, _ptr(a), self._stream()))
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
@@ -556,7 +580,10 @@ def _check_same(ref, shape, **tensors):
 
 def canonical_mu(env, A, s, y, alpha, tol=0.05):
     """The canonical chart (chart_mode='canonical') as a primitive on the GPU: A [n, c, dim_q] = K J (equality row first),
-    s [n, n_g], y [n, c] = psi + Kc c, alpha [n, k]  ->  mu [n, dim_q + n_g] = -Jc^+ y + N alpha."""
+    s [n, n_g], y [n, c] = psi + Kc c, alpha [n, k]  ->  mu [n, dim_q + n_g] = -Jc^+ y + N alpha.
+    Contract: the entries of A that the environment's constraint Jacobian leaves STRUCTURALLY zero (planar / iiwa joint-limit
+    rows off their diagonal; iiwa row 4, joints 3..6) are not read -- a general matrix is treated as having zeros there
+    (include/atacom_hip.h)."""
     lib = _lib.load()
     env_id = _ENV_IDS[env] if isinstance(env, str) else int(env)
     d = _lib.get_dims(env_id)

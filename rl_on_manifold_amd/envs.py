@@ -109,18 +109,18 @@ class CircleEnvTerminated(CircleEnvAtacom):
 
 class _AirHockeyFacade(_Facade):
     def _init_common(self, task, gamma, horizon, timestep, n_intermediate_steps, env_noise, obs_noise, obs_delay,
-                     Kc, random_init, action_penalty, device, dtype):
+                     Kc, random_init, action_penalty, device, dtype, seed=0):
         if task not in ('H', 'D'):
             raise ValueError("task must be 'H' or 'D', got %r" % (task,))
         if task == 'D' and self._env_name != 'planar':
             raise NotImplementedError       # as the reference does for the iiwa wrapper (iiwa_hit_atacom.py:20-21)
         self.task = task
-        if env_noise or obs_noise or obs_delay:
-            raise NotImplementedError("domain randomisation (env_noise / obs_noise / obs_delay) is out of scope")
         self.random_init = random_init
+        # env_noise / obs_noise / obs_delay (env_base.py:176-180, env_single.py:105-107,114-117): drawn on the device; seed()
+        # before the first reset has no effect on them -- pass `seed` here
         self._make(horizon=horizon, gamma=gamma, Kc=Kc, time_step=timestep,
                    n_intermediate_steps=n_intermediate_steps, action_penalty=action_penalty, device=device,
-                   dtype=dtype, task=task)
+                   dtype=dtype, task=task, env_noise=env_noise, obs_noise=obs_noise, obs_delay=obs_delay, seed=seed)
         st = self._engine.get_state()[0].cpu().numpy()
         nq = self.dims['q']
         self._init_q = st[:nq].astype(np.float64)
@@ -156,9 +156,9 @@ class AirHockeyPlanarAtacom(_AirHockeyFacade):
 
     def __init__(self, task='H', gamma=0.99, horizon=120, timestep=1 / 240., n_intermediate_steps=4,
                  debug_gui=False, env_noise=False, obs_noise=False, obs_delay=False, Kc=240., random_init=False,
-                 action_penalty=1e-3, device='cuda:0', dtype=torch.float32):
+                 action_penalty=1e-3, device='cuda:0', dtype=torch.float32, seed=0):
         self._init_common(task, gamma, horizon, timestep, n_intermediate_steps, env_noise, obs_noise, obs_delay,
-                          Kc, random_init, action_penalty, device, dtype)
+                          Kc, random_init, action_penalty, device, dtype, seed)
 
 
 class AirHockeyIiwaAtacom(_AirHockeyFacade):
@@ -166,9 +166,9 @@ class AirHockeyIiwaAtacom(_AirHockeyFacade):
 
     def __init__(self, task='H', gamma=0.99, horizon=120, timestep=1 / 240., n_intermediate_steps=4,
                  debug_gui=False, env_noise=False, obs_noise=False, obs_delay=False, Kc=240., random_init=False,
-                 action_penalty=1e-3, device='cuda:0', dtype=torch.float32):
+                 action_penalty=1e-3, device='cuda:0', dtype=torch.float32, seed=0):
         self._init_common(task, gamma, horizon, timestep, n_intermediate_steps, env_noise, obs_noise, obs_delay,
-                          Kc, random_init, action_penalty, device, dtype)
+                          Kc, random_init, action_penalty, device, dtype, seed)
 
 
 class VectorizedAtacomEnv:

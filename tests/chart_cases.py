@@ -15,6 +15,26 @@ def init_q(name, B, rng, sigma=0.05):
     return q0 + (rng.normal(0, sigma, (B, len(q0))) if name != 'circle' else 0.0)
 
 
+def away_init_q(B, rng, sigma=0.3, min_abs=0.1):
+    """iiwa joint states AWAY from the reset pose: q_init + N(0, sigma^2), Newton steps onto the
+    equality constraint (tip height), kept only if every inequality holds with a margin and NO joint is within `min_abs`
+    rad of zero -- the reset pose is exactly planar (q1 = q3 = q5 = 0), the regime where LAPACK's null basis is
+    ill-determined.  About one draw in ten survives."""
+    spec = SPECS['iiwa']()
+    keep, have = [], 0
+    while have < B:
+        q = IIWA_INIT_Q + rng.normal(0, sigma, (4 * B, 6))
+        for _ in range(3):
+            fun, J, _ = ob.constraint_terms(spec, q, np.zeros_like(q))
+            Jf = J[:, 0, :]
+            q = q - Jf * (fun[:, :1] / (Jf * Jf).sum(1, keepdims=True))
+        fun, _, _ = ob.constraint_terms(spec, q, np.zeros_like(q))
+        ok = (fun[:, 1:] < -1e-3).all(1) & (np.abs(fun[:, 0]) < 1e-6) & (np.abs(q) > min_abs).all(1)
+        keep.append(q[ok])
+        have += int(ok.sum())
+    return np.concatenate(keep)[:B]
+
+
 def rollout_systems(name, B=256, T=40, seed=0, stride=3):
     """Every `stride`-th (Jc, rhs, N) the reference-chart oracle factorised during a B x T rollout, as
     dict(A [n, c, q], s [n, g], y [n, c], Jc [n, c, q + g], Nr [n, q + g, k] = the reference's rref'd basis,

@@ -175,6 +175,7 @@ class SensitivityRecorder:
                 if E[t, b] > C_SENS * S[t, b] + FLOOR:
                     unexplained.append((int(t), int(b), float(E[t, b]), float(S[t, b]), 'output %d' % self.where[t][b]))
         ratio = E / (C_SENS * S + FLOOR)
+        self.bound = C_SENS * S + FLOOR                       # kept for followed_chart_errors
         vac = float(np.mean(C_SENS * S + FLOOR > VACUOUS))
         summary = ('%s: %d samples, err median %.2e / p99.9 %.2e / max %.2e; err / (C sens + floor) max %.2f; '
                    '%d samples needed the deep probe; bound vacuous (> %.0e) on %.2f %% of the samples (ceiling %.1f %%)'
@@ -188,6 +189,48 @@ class SensitivityRecorder:
         assert not unexplained, 'UNEXPLAINED float32 errors (t, env, err, sens, where): %s | %s' % (unexplained[:10], summary)
         assert np.median(E) < 2e-5 and np.quantile(E, 0.99) < 2e-3, summary      # and the bulk is at rounding level
         return summary
+
+
+def skip_pattern_of_rref(Nr, tol=1e-6):
+    """The pivot-or-skip decisions behind an rref'd null basis Nr [B, n, k] (null_space_coordinate.rref, column vectors):
+    row j of Nr is the unit vector e_i exactly when column j was the i-th pivot column; a column that was skipped (its
+    candidates <= the tolerance, zeroed from row i down) carries zeros in the entries i.. only.  Returns bool [B, n]: True =
+    skipped (columns after the last pivot are reported as pivots -- they are never tested)."""
+    Nr = np.asarray(Nr, dtype=np.float64)
+    B, n, k = Nr.shape
+    i = np.zeros(B, dtype=np.int64)
+    skip = np.zeros((B, n), dtype=bool)
+    eye = np.eye(k)
+    for j in range(n):
+        active = i < k
+        unit = np.abs(Nr[:, j, :] - eye[np.minimum(i, k - 1)]).max(1) < tol
+        piv = active & unit
+        skip[:, j] = active & ~unit
+        i = i + piv
+    return skip
+
+
+def followed_chart_errors(rec, follow_fn, tol=1e-4, only_vacuous=True):
+    """VERDICT r3 item 3b.  For the samples whose sensitivity bound says nothing (> VACUOUS), compare the device with the
+    float64 oracle FORCED ONTO THE DEVICE'S OWN CHART DECISIONS: follow_fn(Jc [b, c, n]) -> bool [b, n] (the pivot / skip
+    pattern the device's float32 rref takes on these matrices, read off atacom_nullspace).  Call after finish().
+    Returns (number of such samples, their errors against the following oracle, their errors against the plain oracle)."""
+    E = np.array(rec.err)
+    sel = rec.bound > VACUOUS if only_vacuous else np.ones_like(rec.bound, dtype=bool)
+    e_follow, e_plain = [], []
+    for t in range(E.shape[0]):
+        idx = np.nonzero(sel[t])[0]
+        if not len(idx):
+            continue
+        sub = slice_env(rec.snaps[t], idx)
+        sub.chart_follow = follow_fn
+        out = rec.step_fn(sub, tuple(x[idx] for x in rec.inputs[t]))
+        dev = rec.dev[t][idx]
+        e_follow.append((np.abs(dev - out) / np.maximum(1.0, np.abs(out))).max(1))
+        e_plain.append(E[t, idx])
+    if not e_follow:
+        return 0, np.zeros(0), np.zeros(0)
+    return int(sel.sum()), np.concatenate(e_follow), np.concatenate(e_plain)
 
 
 def assert_matrix_fn_explained(fn, A, dev_out, what='', seed=0, max_vacuous=0.4):

@@ -83,3 +83,32 @@ def test_batched_solver_matches_golden(golden, name):
     assert np.allclose(R, g[name + '_rref'], atol=1e-9 * max(1, np.abs(g[name + '_rref']).max()))
     # invariants: Jc Jc^+ = I always; Jc N = 0 for the orthonormal basis
     assert np.abs(np.einsum('bcn,bnk->bck', Jc, N)).max() < 1e-12
+
+
+def test_rref_on_forced_decisions_and_their_decoding():
+    """tests/parity_tools.skip_pattern_of_rref reads the pivot / skip decisions off an rref'd basis, and
+    rref_tol(forced_skip=...) replays them: on iiwa J_c matrices around the reset pose (40 % of which take the tolerance
+    branch) decoding the oracle's own output and forcing it reproduces that output exactly; forcing the no-skip chart
+    changes exactly the matrices that had skipped."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from parity_tools import skip_pattern_of_rref
+    from oracle import atacom_scalar as osc, atacom_batched as ob
+    rng = np.random.default_rng(0)
+    spec = osc.iiwa_spec()
+    B = 600
+    q = np.array([0.0, 0.7135214629060707, 0.0, -0.5024756033561426, 0.0, 1.9256631778550268]) + rng.normal(0, 0.05, (B, 6))
+    o = ob.BatchedAtacomEnv(spec, B, init_q=q)
+    fun, J, _ = ob.constraint_terms(spec, o.q, o.dq)
+    Jc = np.zeros((B, 12, 17))
+    Jc[:, :, :6] = spec.K[None, :, None] * J + 0.0
+    idx = np.arange(11)
+    Jc[:, 1 + idx, 6 + idx] = o.s
+    _, N = ob.bidiag_solve_null(Jc, np.zeros((B, 12)), 5)
+    skipped = np.zeros(B, bool)
+    Nr = ob.rref_tol(N, 0.05, None, skipped)
+    pat = skip_pattern_of_rref(Nr)
+    assert 0.2 < skipped.mean() < 0.6 and np.array_equal(pat.any(1), skipped)
+    assert np.abs(ob.rref_tol(N, 0.05, forced_skip=pat) - Nr).max() == 0.0
+    other = ob.rref_tol(N, 0.05, forced_skip=np.zeros_like(pat))
+    assert np.array_equal(np.abs(other - Nr).max((1, 2)) > 1e-9, skipped)
