@@ -102,6 +102,23 @@ def algorithmic_flops_canonical(env):
     return sub * per_sub + 2 * fk + 4 * M * nq
 
 
+def algorithmic_flops_dyn():
+    """FLOPs the rigid-body mode (row N4, dynamics_mode 1 / 2) adds to one iiwa env-step: per physics sub-step the nine-body
+    chain, one Newton-Euler pass, the 9 x 6 mass-matrix rows, servo set-points, torque, Cholesky solve -- counted loop by
+    loop from rl_on_manifold_amd/csrc/atacom_dynamics.h and atacom_kernels.h:rigid_body_substep (FMA = 2, a cross product
+    = 9, a symmetric 3 x 3 product = 15, sincos / acos = 20; selects, compares and moves not counted)."""
+    cross, sym, trig = 9, 15, 20
+    body = 18 + 45 + 30                                               # centre of mass, R I, (R I) R^T
+    chain = 7 * (6 + 18 + trig + body) + 6 + 2 * (trig + 18 + body)   # seven arm joints, the universal joint
+    fwd = 3 + 3 * cross + 6 + 3 + cross + 6 + 3 + 3 * cross + 9 + 2 * sym + cross + 3       # per body, base to tip
+    bwd = 3 + cross + 3 + 3 + 3 + cross + 6 + 5                                              # per joint, tip to base
+    rnea = 9 * (fwd + bwd)
+    crba = 6 * cross + 9 * 36 + 9 * (cross + 6 + sym + cross + 3) + 3 * cross + 3 * 13 + 39 * 11   # composites, rows, entries
+    servo = (2 * cross + 12 + 3 + 5 + trig + 6) + (trig + cross + 12) + 3 * 8
+    solve = 6 * (2 * 9) + 6 * (2 * 5) + (6 ** 3 // 3 + 2 * 36 + 30) + 12                    # torque, right-hand side, Cholesky
+    return SHAPES['iiwa'][4] * (chain + rnea + crba + servo + solve)
+
+
 # ------------------------------------------------------------------------------------------ rank spawning
 def _free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -246,10 +263,11 @@ def graphed_step_us(env, actions, n=20, reps=30):
     return (time.perf_counter() - t0) / (reps * n) * 1e6
 
 
-def roofline_objects(name, B, kern_ms, traffic=None, chart='reference'):
+def roofline_objects(name, B, kern_ms, traffic=None, chart='reference', dyn=False):
     """(roofline, roofline_hbm): the binding roof first -- fp32 vector ALU -- then the HBM view of the same kernel."""
-    algo_bytes = ALGO_BYTES[name] * B
-    flops = (algorithmic_flops_canonical(name) if chart == 'canonical' else algorithmic_flops(name)) * B
+    algo_bytes = (ALGO_BYTES[name] + (48 if dyn else 0)) * B          # dyn: + the six servo-joint values read and written
+    flops = ((algorithmic_flops_canonical(name) if chart == 'canonical' else algorithmic_flops(name))
+             + (algorithmic_flops_dyn() if dyn else 0)) * B
     gbs = algo_bytes / (kern_ms * 1e-3) / 1e9
     tf = flops / (kern_ms * 1e-3) / 1e12
     return ({'bound': 'valu_f32', 'achieved': tf, 'peak': VALU_F32_PEAK_TF, 'unit': 'TFLOP/s',
@@ -258,7 +276,21 @@ def roofline_objects(name, B, kern_ms, traffic=None, chart='reference'):
              'note': 'fp32 vector ALU is the binding roof (130 FLOP/B, ridge at 20); traffic = measured HBM bytes per '
                      'launch (FETCH_SIZE + WRITE_SIZE, profiles/traffic_*.json) next to roofline_hbm.algorithmic_bytes_per_launch'},
             {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
-             'traffic': traffic, 'algorithmic_bytes_per_launch': algo_bytes, 'kernel_ms': kern_ms})
+             'traffic': traffic, 'algorithmic_bytes_per_launch': algo_bytes, 'kernel_ms': kern_ms,
+             # > 1: bytes that travel without being asked for (the state moves in whole groups of four fields)
+             'traffic_over_algorithmic': (traffic / algo_bytes) if traffic else None})
+
+
+def committed_kernel_us(csv_name, kernel_substr):
+    """Average duration (us) of a kernel from a committed rocprofv3 --stats summary under profiles/ (None if absent)."""
+    import csv
+    try:
+        for r in csv.DictReader(open(os.path.join(ROOT, 'profiles', csv_name))):
+            if kernel_substr in r['Name']:
+                return float(r['AverageNs']) / 1e3
+    except Exception:  # noqa: BLE001
+        pass
+    return None
 
 
 def main():
@@ -461,9 +493,9 @@ def main():
     return result
 
 
-def measured_traffic(name, chart='reference'):
+def measured_traffic(name, chart='reference', dyn=False):
     """HBM bytes per launch of the step kernel at the BASELINE batch, from the committed counter passes."""
-    tpath = os.path.join(ROOT, 'profiles', 'traffic_%s%s.json' % (name, '_canonical' if chart == 'canonical' else ''))
+    tpath = os.path.join(ROOT, 'profiles', 'traffic_%s%s.json' % (name, '_dyn' if dyn else ('_canonical' if chart == 'canonical' else '')))
     try:
         return json.load(open(tpath)).get('hbm_bytes_per_launch')
     except Exception:  # noqa: BLE001
@@ -530,11 +562,22 @@ def secondary_records(dev, gen, K, W, sync_all, max_over_ranks):
         roll = 5 * 120 * B / (time.perf_counter() - t0)
         g_us = graphed_step_us(env, acts)
         roof, roof_hbm = roofline_objects(name, B, kern_ms, measured_traffic(name))
-        out.append({'workload': WORKLOAD[name] + ', batch %d' % B, 'value': B * K / el, 'unit': 'env-steps/s',
-                    'ms_per_step': el / K * 1e3, 'blocks': len(secs), 'max_abs_c': c_max, 'c_avg': c_avg,
-                    'c_dq_max': c_dq, 'rollout_kernel_env_steps_per_s': roll,
-                    'hip_graph_20_steps_us_per_step': g_us, 'roofline': roof,
-                    'roofline_hbm': roof_hbm})
+        rec = {'workload': WORKLOAD[name] + ', batch %d' % B, 'value': B * K / el, 'unit': 'env-steps/s',
+               'ms_per_step': el / K * 1e3, 'blocks': len(secs), 'max_abs_c': c_max, 'c_avg': c_avg,
+               'c_dq_max': c_dq, 'rollout_kernel_env_steps_per_s': roll,
+               'hip_graph_20_steps_us_per_step': g_us, 'roofline': roof,
+               'roofline_hbm': roof_hbm}
+        if name == 'circle':
+            # this configuration is bound by the host's launch path, not by the kernel: the fraction above divides by the time
+            # between launches; beside it the kernel-only view, from the committed rocprofv3 kernel statistics of this workload
+            k_us = committed_kernel_us('r04_rocprofv3_kernel_stats_circle.csv', 'k_step<float, atacom::Circle') or \
+                committed_kernel_us('r03_rocprofv3_kernel_stats_circle.csv', 'k_step<float, atacom::Circle')
+            rec['launch_bound'] = True
+            if k_us:
+                rk, _ = roofline_objects(name, B, k_us * 1e-3, measured_traffic(name))
+                rec['roofline_kernel_only'] = {'kernel_us_rocprofv3': k_us, 'frac': rk['frac'], 'achieved': rk['achieved'],
+                                               'unit': rk['unit'], 'source': 'profiles/r0x_rocprofv3_kernel_stats_circle.csv'}
+        out.append(rec)
         env.close()
     # the iiwa headline workload through the allocating Python surface (step(): clones + bool conversion per call), and
     # in the opt-in rigid-body mode (row N4)
@@ -577,6 +620,9 @@ def secondary_records(dev, gen, K, W, sync_all, max_over_ranks):
             rec['rollout_kernel_env_steps_per_s'] = 5 * 120 * B / (time.perf_counter() - t0)
             rec['roofline'], rec['roofline_hbm'] = roofline_objects('iiwa', B, kern_ms, measured_traffic('iiwa', 'canonical'),
                                                                     'canonical')
+        if 'dynamics_mode' in kw:
+            rec['roofline'], rec['roofline_hbm'] = roofline_objects('iiwa', B, kern_ms, measured_traffic('iiwa', dyn=True),
+                                                                    dyn=True)
         out.append(rec)
         env.close()
     return out

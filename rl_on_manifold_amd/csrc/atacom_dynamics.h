@@ -269,25 +269,11 @@ __device__ __forceinline__ void chol_solve(T (&A)[NR][NB], T (&b)[NB]) {
 // ---- servo set-points (env_single.py:137-185) from the arm's forward kinematics
 // joint 7: the angle that keeps the striker's y axis horizontal, evaluated with joint 7 at zero (env_single.py:139-142)
 template <typename T>
-__device__ __forceinline__ T joint7_target(const T (&q6)[6], T q7_cur) {
-    T q9[9] = {q6[0], q6[1], q6[2], q6[3], q6[4], q6[5], T(0), T(0), T(0)};
-    // only the orientation of link_7 at q7 = 0 is needed: its y and z axes
-    T X[3] = {T(1), T(0), T(0)}, Y[3] = {T(0), T(1), T(0)}, Z[3] = {T(0), T(0), T(1)};
-    constexpr int kind[7] = {0, 1, 1, 2, 1, 2, 1};
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        T nx[3], ny[3], nz[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            if (kind[i] == 0) { nx[d] = X[d]; ny[d] = Y[d]; nz[d] = Z[d]; }
-            else if (kind[i] == 1) { nx[d] = -X[d]; ny[d] = Z[d]; nz[d] = Y[d]; }
-            else { nx[d] = X[d]; ny[d] = Z[d]; nz[d] = -Y[d]; }
-        }
-        T s, c;
-        num<T>::sincos(q9[i], &s, &c);
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { X[d] = num<T>::fma(c, nx[d], s * ny[d]); Y[d] = num<T>::fma(c, ny[d], -(s * nx[d])); Z[d] = nz[d]; }
-    }
+__device__ __forceinline__ T joint7_target(const T (&Y)[3], const T (&Z)[3], T q7_cur) {
+    // Y, Z: the y and z axes of link_7 with joint 7 AT ZERO.  They come from the chain the dynamics have just evaluated:
+    // joint 7's origin frame maps link_6's (x, y, z) to (-x, z, y) (urdf:295, kind 1 in iiwa_chain9), so at q7 = 0 link_7's
+    // y axis is link_6's z axis = the axis of joint 6 (Chain9::a[5]) and its z axis is joint 7's own axis (a[6]) -- no second
+    // pass through the seven joint rotations (it had cost seven sincos and ~400 instructions per physics sub-step).
     const T down[3] = {T(0), T(0), T(-1)};
     T yd[3];
     cross3(down, Z, yd);                                                          // :144

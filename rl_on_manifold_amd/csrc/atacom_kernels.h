@@ -335,6 +335,7 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
 #pragma unroll
     for (int i = 0; i < 3; ++i) { q9[6 + i] = st.qx[i]; dq9[6 + i] = st.dqx[i]; }
     Chain9<T> ch;
+    ATACOM_MARK("DYN_chain"); ATACOM_PHASE();
     iiwa_chain9(q9, ch);
     // The equation of motion is linear in the accelerations, tau = M(q) ddq + h(q, dq), so ONE recursive Newton-Euler
     // pass (h: all accelerations zero) and the mass-matrix rows the step needs anyway replace the two passes of the literal
@@ -344,11 +345,13 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
     T zero9[9], h9[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) zero9[i] = T(0);
+    ATACOM_MARK("DYN_rnea"); ATACOM_PHASE();
     rnea9<T, true>(ch, dq9, zero9, h9);
+    ATACOM_MARK("DYN_crba"); ATACOM_PHASE();
     T Ml[9][6], Mss[3];                             // rows 0..5: M_cc (lower triangle); rows 6..8: M_sc = M_cs^T
     crba<T, 6, 9>(ch, Ml, Mss);
-    const T q6[6] = {st.q[0], st.q[1], st.q[2], st.q[3], st.q[4], st.q[5]};
-    const T tgt[3] = {joint7_target(q6, st.qx[0]), universal_target(ch.a[6], ch.a[7]), T(0)};
+    ATACOM_MARK("DYN_servo"); ATACOM_PHASE();
+    const T tgt[3] = {joint7_target(ch.a[5], ch.a[6], st.qx[0]), universal_target(ch.a[6], ch.a[7]), T(0)};
     constexpr T vmax[3] = {T(1.5 * 2.356194490192345), T(1.5 * 3.1415926), T(1.5 * 3.1415926)};     // urdf:297,384,397
     constexpr T effort_s[3] = {T(40), T(10), T(10)};                                                // urdf:297,384,400
     T dds[3];
@@ -378,7 +381,9 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
         for (int s2 = 0; s2 < 3; ++s2) r = num<T>::fma(-Ml[6 + s2][i], dds[s2], r);
         rhs[i] = r;
     }
+    ATACOM_MARK("DYN_solve"); ATACOM_PHASE();
     chol_solve<T, 6, 9>(Ml, rhs);
+    ATACOM_MARK("DYN_end"); ATACOM_PHASE();
 #pragma unroll
     for (int i = 0; i < 6; ++i) ddq[i] = rhs[i];
 #pragma unroll
@@ -984,6 +989,86 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
     pli(ip, L::I_CNT, b) += n_steps;
     store_state<T, E>(f, ip, B, b, st);
     if constexpr (DYN) store_aux<T, E>(f, B, b, st);
+}
+
+// ------------------------------------------------------------------ step server (an experiment)
+// A PERSISTENT launch that keeps every environment's state in registers -- as k_rollout does -- but takes the action of
+// each step from the caller while it runs: per step a workgroup waits for the device flag `go` to pass the step's number
+// (written from the caller's stream, hipStreamWriteValue32), reads its actions, steps, writes observation / reward / flags
+// and adds one to the counter `done`, on which the caller's stream waits (hipStreamWaitValue32).  What it removes is the
+// ~3.4 us per atacom_step launch that are not instructions (dispatch skew, first loads after the kernel-boundary cache
+// invalidate, store tail: DESIGN.md section 6); what it adds is the flag round trip.  Visibility follows the inter-workgroup
+// rule of the CDNA guide: agent-scope acquire after the flag is seen (drops the L1 lines of the action buffer, which are
+// re-written at the same addresses every step), agent-scope release before the counter is bumped.
+// go < 0: stop.  A flag that does not move for `spin_limit` polls ends the launch as well (err = 1, `done` jumps so that
+// no stream stays blocked on it): a forgotten submit must not hang the device.
+template <typename T, typename E, int LANES, bool HOLD, int CHART = 0>
+__global__ void __launch_bounds__(BLOCK<LANES>) k_server(const Params<T> P, int max_steps, T* __restrict__ f,
+                                                 int* __restrict__ ip, const T* action, T* obs, T* reward,
+                                                 uint8_t* absorbing, uint8_t* last, int* go, unsigned int* done, int* err,
+                                                 long long spin_limit) {
+    using L = Planes<E>;
+    __shared__ int sh_go;
+    const int B = P.batch;
+    const int gt = blockIdx.x * BLOCK<LANES> + threadIdx.x;
+    const int b = gt / LANES;
+    const int lq = gt % LANES;
+    if (b >= B) return;                               // (whole waves only -- the host rounds the launch to full workgroups)
+    const EnvRef<T, false> ref{f, ip, B, b, true};
+    EnvState<T, E> st;
+    load_state<T, E>(f, ip, B, b, st);
+    T ssum = T(0), scmax = pl<E>(f, L::SCMAX, B, b), sdq = pl<E>(f, L::SDQMAX, B, b);
+    int served = 0;
+#pragma unroll 1
+    for (int t = 0; t < max_steps; ++t) {
+        if (threadIdx.x == 0) {
+            int v = 0;
+            long long spins = 0;
+            do {
+                v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (v > t || v < 0) break;
+                __builtin_amdgcn_s_sleep(8);
+            } while (++spins < spin_limit);
+            sh_go = v;
+        }
+        __syncthreads();
+        const int v = sh_go;
+        __syncthreads();                              // (sh_go is rewritten by thread 0 in the next iteration)
+        if (v < 0) break;
+        if (v <= t) {                                 // timed out
+            if (threadIdx.x == 0) {
+                atomicExch(err, 1);
+                __hip_atomic_fetch_max(done, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        T act[E::NK];
+#pragma unroll
+        for (int k = 0; k < E::NK; ++k) act[k] = action[(size_t)b * E::NK + k];
+        StepOut<T> out;
+        env_step<T, E, LANES, HOLD, false, true, CHART>(P, st, act, out, lq, ref);
+        if (lq == 0) {
+            write_obs<T, E>(P, st, obs + (size_t)b * E::OBS, ref);
+            reward[b] = out.reward;
+            absorbing[b] = out.absorbing ? 1 : 0;
+            if (last) last[b] = out.last ? 1 : 0;
+        }
+        ssum += out.log_avg;
+        scmax = num<T>::max(scmax, out.log_max);
+        sdq = num<T>::max(sdq, out.log_dq);
+        ++served;
+        if (P.auto_reset && out.last) reset_env<T, E>(P, ref, st);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (lq != 0) return;
+    pl<E>(f, L::SSUM, B, b) += ssum;
+    pl<E>(f, L::SCMAX, B, b) = scmax;
+    pl<E>(f, L::SDQMAX, B, b) = sdq;
+    pli(ip, L::I_CNT, b) += served;
+    store_state<T, E>(f, ip, B, b, st);
 }
 
 // Row N2: rollout with the policy MLP evaluated in the kernel (atacom_policy.h).  d_actions_out receives the action

@@ -28,6 +28,15 @@
 #define ATACOM_MARK(name) ((void)0)
 #endif
 
+// phase boundary of the rigid-body sub-step: the scheduler may not move instructions across it.  Left to itself it
+// interleaves the chain, the Newton-Euler pass and the composite-inertia pass for instruction-level parallelism, and the
+// union of their live ranges no longer fits the register file next to the held solver state (-DATACOM_NO_PHASE: A/B build)
+#ifdef ATACOM_NO_PHASE
+#define ATACOM_PHASE() ((void)0)
+#else
+#define ATACOM_PHASE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 namespace atacom {
 
 template <typename T> struct num;
