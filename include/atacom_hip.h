@@ -253,28 +253,6 @@ int atacom_snapshot_restore(atacom_handle* h, const void* d_image, void* stream)
 int atacom_get_aux_state(atacom_handle* h, void* d_aux, void* stream);
 int atacom_set_aux_state(atacom_handle* h, const void* d_aux, void* stream);
 
-/* Step server -- an experiment (measured result and verdict: profiles/r04_step_server.md, DESIGN.md
- * section 6).  atacom_server_start launches ONE persistent kernel (on a stream of the library's own) that keeps the state of
- * every environment in registers, as atacom_rollout does, and then serves one env step per atacom_server_submit from the
- * FIXED buffers given here -- what a vectorised agent with its policy in torch calls per step instead of atacom_step:
- *   ... the caller's kernels write d_action on `stream` ...
- *   atacom_server_submit(h, stream)   enqueues on `stream`: a flag write that releases the step, and a wait for its
- *                                      completion (hipStreamWriteValue32 / hipStreamWaitValue32: no host synchronisation)
- *   ... kernels enqueued on `stream` afterwards see d_obs / d_reward / d_absorbing / d_last of that step ...
- * The launch takes the quad mapping (or one environment per lane) and at most half of the device's SIMDs, so that the
- * caller's kernels run beside it: larger batches are refused (ATACOM_E_UNSUPPORTED), as are float64 handles, the rigid-body
- * mode and the noise options.  While serving, every other entry point of the handle returns ATACOM_E_INVALID (the state is in
- * the launch); atacom_server_stop ends it and writes the state back.  NEVER synchronise the whole device
- * (hipDeviceSynchronize, hipFree) while a server runs: that waits for the launch, which waits for submissions -- it ends
- * only when `timeout_s` (default 5 s, counted in polls of the flag) passes without one, and stop then reports the time-out.
- * transport: how a submission reaches the launch.  0 = hipStreamWriteValue32 + hipStreamWaitValue32 on the caller's stream
- * (flags in signal memory); 1 = one single-wave kernel on the caller's stream that sets the flag and spins on the counter
- * (flags in device memory).  atacom_server_stop sends the stop flag down `stream` (the stream of the submissions). */
-int atacom_server_start(atacom_handle* h, const void* d_action, void* d_obs, void* d_reward, uint8_t* d_absorbing,
-                        uint8_t* d_last, int32_t max_steps, double timeout_s, int32_t transport);
-int atacom_server_submit(atacom_handle* h, void* stream);
-int atacom_server_stop(atacom_handle* h, void* stream);
-
 /* obs_delay (cfg.obs_delay = 1; planar / iiwa handles): the low-pass state behind the observation's velocities,
  * d_filter [batch, 3 + dim_q] = [puck vx, vy, yaw rate, joint velocities] as the last observation showed them
  * (obs_prev[3:6] and the robot-velocity slice of env_single.py:114-119).  Every reset re-initialises it to the unfiltered

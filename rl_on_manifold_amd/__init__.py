@@ -11,7 +11,7 @@ from ._lib import AtacomError, LIB_PATH  # noqa: F401
 def __getattr__(name):
     # torch is imported lazily so that `import rl_on_manifold_amd` (and the build) stay cheap
     if name in ('BatchedAtacomEnv', 'nullspace', 'constraint_terms', 'MlpPolicy', 'inverse_dynamics', 'forward_dynamics',
-                'GraphedRollout', 'canonical_mu', 'StepServer'):
+                'GraphedRollout', 'canonical_mu'):
         from . import engine
         return getattr(engine, name)
     if name in ('CircleEnvAtacom', 'AirHockeyPlanarAtacom', 'AirHockeyIiwaAtacom', 'CircleEnvErrorCorrection',

@@ -18,8 +18,7 @@ EXPORTS = ['atacom_snapshot_bytes', 'atacom_snapshot_save', 'atacom_snapshot_res
            'atacom_inverse_dynamics', 'atacom_forward_dynamics', 'atacom_default_config', 'atacom_get_dims', 'atacom_create', 'atacom_destroy', 'atacom_reset',
            'atacom_step', 'atacom_rollout', 'atacom_get_stats', 'atacom_get_state', 'atacom_set_state',
            'atacom_nullspace', 'atacom_constraint_terms', 'atacom_step_masked', 'atacom_canonical_mu', 'atacom_last_error', 'atacom_version', 'atacom_get_lanes',
-           'atacom_get_filter_state', 'atacom_set_filter_state', 'atacom_server_start', 'atacom_server_submit',
-           'atacom_server_stop']
+           'atacom_get_filter_state', 'atacom_set_filter_state']
 
 
 class AtacomConfig(C.Structure):
@@ -99,9 +98,6 @@ def load():
     lib.atacom_snapshot_save.argtypes = [vp, vp, vp]
     lib.atacom_snapshot_restore.argtypes = [vp, vp, vp]
     lib.atacom_set_aux_state.argtypes = [vp, vp, vp]
-    lib.atacom_server_start.argtypes = [vp, vp, vp, vp, u8p, u8p, i32, C.c_double, i32]
-    lib.atacom_server_submit.argtypes = [vp, vp]
-    lib.atacom_server_stop.argtypes = [vp, vp]
     lib.atacom_get_filter_state.argtypes = [vp, vp, vp]
     lib.atacom_set_filter_state.argtypes = [vp, vp, vp]
     lib.atacom_inverse_dynamics.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp]

@@ -141,15 +141,6 @@ struct atacom_handle {
     double* partial_host;
     void* snap_dev;       // the header every snapshot image starts with (SnapHeader), device copy
     void* snap_host;      // pinned: atacom_snapshot_restore reads an image's header into it
-    // step server (atacom_server_*): while `serving` the state lives in the registers of a persistent launch
-    bool serving;
-    hipStream_t srv_stream;            // non-blocking: the launch itself
-    int* srv_go;                       // signal memory: number of steps submitted (-1: stop)
-    unsigned int* srv_done;            // signal memory: workgroups x steps served
-    int* srv_err;
-    int srv_blocks, srv_t, srv_max;
-    int srv_transport;                 // 0: hipStreamWriteValue32 / hipStreamWaitValue32; 1: one tiny kernel per submission
-    long long srv_spin;
 };
 
 // What a snapshot image starts with: enough of the configuration to refuse an image of another handle shape instead of
@@ -314,8 +305,6 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
     h->ops = ops;
     h->f = nullptr; h->ip = nullptr; h->partial_dev = nullptr; h->partial_host = nullptr;
     h->snap_dev = nullptr; h->snap_host = nullptr;
-    h->serving = false; h->srv_stream = nullptr; h->srv_go = nullptr; h->srv_done = nullptr;
-    h->srv_err = nullptr; h->srv_blocks = h->srv_t = h->srv_max = 0; h->srv_transport = 0; h->srv_spin = 0;
     const size_t B = (size_t)cfg->batch;
     void* drow = nullptr;
     // default initial state for every env, then a full reset
@@ -362,12 +351,7 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
 
 int atacom_destroy(atacom_handle* h) {
     if (!h) return ATACOM_OK;
-    if (h->serving) (void)atacom_server_stop(h, nullptr);
     DeviceGuard guard(h->device);
-    if (h->srv_go) (void)hipFree(h->srv_go);
-    if (h->srv_done) (void)hipFree(h->srv_done);
-    if (h->srv_err) (void)hipFree(h->srv_err);
-    if (h->srv_stream) (void)hipStreamDestroy(h->srv_stream);
     if (h->f) (void)hipFree(h->f);
     if (h->ip) (void)hipFree(h->ip);
     if (h->partial_dev) (void)hipFree(h->partial_dev);
@@ -380,7 +364,6 @@ int atacom_destroy(atacom_handle* h) {
 
 int atacom_reset(atacom_handle* h, const uint8_t* d_mask, const void* d_init_state, void* d_obs, void* stream) {
     if (!h) return fail(ATACOM_E_INVALID, "atacom_reset: null handle");
-    if (h->serving) return fail(ATACOM_E_INVALID, "atacom_reset: the handle is serving (atacom_server_start): its state lives in the running launch until atacom_server_stop");
     ON_DEVICE(h);
     h->ops->reset(h->cfg, h->f, h->ip, d_mask, d_init_state, d_obs, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -390,7 +373,6 @@ int atacom_reset(atacom_handle* h, const uint8_t* d_mask, const void* d_init_sta
 int atacom_step(atacom_handle* h, const void* d_action, void* d_obs, void* d_reward, uint8_t* d_absorbing,
                 uint8_t* d_last, void* stream) {
     if (!h) return fail(ATACOM_E_INVALID, "atacom_step: null handle");
-    if (h->serving) return fail(ATACOM_E_INVALID, "atacom_step: the handle is serving (atacom_server_start): its state lives in the running launch until atacom_server_stop");
     if (!d_action || !d_obs || !d_reward || !d_absorbing)
         return fail(ATACOM_E_INVALID, "atacom_step: d_action, d_obs, d_reward and d_absorbing are required");
     ON_DEVICE(h);
@@ -403,7 +385,6 @@ int atacom_step(atacom_handle* h, const void* d_action, void* d_obs, void* d_rew
 int atacom_step_masked(atacom_handle* h, const uint8_t* d_mask, const void* d_action, void* d_obs, void* d_reward,
                        uint8_t* d_absorbing, uint8_t* d_last, void* stream) {
     if (!h) return fail(ATACOM_E_INVALID, "atacom_step_masked: null handle");
-    if (h->serving) return fail(ATACOM_E_INVALID, "atacom_step_masked: the handle is serving (atacom_server_start): its state lives in the running launch until atacom_server_stop");
     if (!d_action || !d_obs || !d_reward || !d_absorbing)
         return fail(ATACOM_E_INVALID, "atacom_step_masked: d_action, d_obs, d_reward and d_absorbing are required");
     ON_DEVICE(h);
@@ -416,7 +397,6 @@ int atacom_step_masked(atacom_handle* h, const uint8_t* d_mask, const void* d_ac
 int atacom_rollout(atacom_handle* h, int32_t n_steps, const void* d_actions, void* d_obs, void* d_next_obs,
                    void* d_reward, uint8_t* d_absorbing, uint8_t* d_last, void* stream) {
     if (!h) return fail(ATACOM_E_INVALID, "atacom_rollout: null handle");
-    if (h->serving) return fail(ATACOM_E_INVALID, "atacom_rollout: the handle is serving (atacom_server_start): its state lives in the running launch until atacom_server_stop");
     if (n_steps <= 0) return fail(ATACOM_E_INVALID, "atacom_rollout: n_steps must be positive");
     if (!d_actions || !d_obs || !d_reward || !d_absorbing || !d_last)
         return fail(ATACOM_E_INVALID, "atacom_rollout: all buffers except d_next_obs are required");
@@ -431,7 +411,6 @@ int atacom_rollout_mlp(atacom_handle* h, int32_t n_steps, const atacom_mlp* net,
                        void* d_next_obs, void* d_actions, void* d_reward, uint8_t* d_absorbing, uint8_t* d_last,
                        void* stream) {
     if (!h || !net) return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: null handle / network");
-    if (h->serving) return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: the handle is serving (atacom_server_start): its state lives in the running launch until atacom_server_stop");
     if (n_steps <= 0) return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: n_steps must be positive");
     const int vrc = check_mlp(h, net, "atacom_rollout_mlp");
     if (vrc != ATACOM_OK) return vrc;
@@ -450,7 +429,6 @@ int atacom_rollout_mlp(atacom_handle* h, int32_t n_steps, const atacom_mlp* net,
 int atacom_rollout_packed(atacom_handle* h, int32_t n_steps, const void* d_actions, const atacom_mlp* net,
                           const void* d_noise, void* d_records, int32_t record_batch_stride, void* stream) {
     if (!h) return fail(ATACOM_E_INVALID, "atacom_rollout_packed: null handle");
-    if (h->serving) return fail(ATACOM_E_INVALID, "atacom_rollout_packed: the handle is serving (atacom_server_start): its state lives in the running launch until atacom_server_stop");
     if (n_steps <= 0) return fail(ATACOM_E_INVALID, "atacom_rollout_packed: n_steps must be positive");
     if (!d_records) return fail(ATACOM_E_INVALID, "atacom_rollout_packed: d_records is required");
     if ((d_actions != nullptr) == (net != nullptr))
@@ -483,7 +461,6 @@ int atacom_get_lanes(const atacom_handle* h, int32_t* out_step_lanes, int32_t* o
 
 int atacom_get_stats(atacom_handle* h, double out[3], int32_t clear, void* stream) {
     if (!h || !out) return fail(ATACOM_E_INVALID, "atacom_get_stats: null argument");
-    if (h->serving) return fail(ATACOM_E_INVALID, "atacom_get_stats: the handle is serving (atacom_server_start): its state lives in the running launch until atacom_server_stop");
     ON_DEVICE(h);
     hipStream_t s = (hipStream_t)stream;
     const int nb = std::min(kStatBlocks, (h->cfg.batch + 255) / 256);
@@ -507,7 +484,6 @@ int atacom_get_stats(atacom_handle* h, double out[3], int32_t clear, void* strea
 
 int atacom_get_state(atacom_handle* h, void* d_state, void* stream) {
     if (!h || !d_state) return fail(ATACOM_E_INVALID, "atacom_get_state: null argument");
-    if (h->serving) return fail(ATACOM_E_INVALID, "atacom_get_state: the handle is serving (atacom_server_start): its state lives in the running launch until atacom_server_stop");
     ON_DEVICE(h);
     h->ops->get_state(h->cfg, h->f, h->ip, d_state, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -516,7 +492,6 @@ int atacom_get_state(atacom_handle* h, void* d_state, void* stream) {
 
 int atacom_set_state(atacom_handle* h, const void* d_state, void* stream) {
     if (!h || !d_state) return fail(ATACOM_E_INVALID, "atacom_set_state: null argument");
-    if (h->serving) return fail(ATACOM_E_INVALID, "atacom_set_state: the handle is serving (atacom_server_start): its state lives in the running launch until atacom_server_stop");
     ON_DEVICE(h);
     h->ops->set_state(h->cfg, h->f, h->ip, d_state, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
@@ -534,7 +509,6 @@ int64_t atacom_snapshot_bytes(const atacom_handle* h) {
 }
 int atacom_snapshot_save(atacom_handle* h, void* d_image, void* stream) {
     if (!h || !d_image) return fail(ATACOM_E_INVALID, "atacom_snapshot_save: null argument");
-    if (h->serving) return fail(ATACOM_E_INVALID, "atacom_snapshot_save: the handle is serving (atacom_server_start): its state lives in the running launch until atacom_server_stop");
     ON_DEVICE(h);
     const size_t B = (size_t)h->cfg.batch, nf = (size_t)h->ops->elem * h->ops->n_planes * B;
     char* img = (char*)d_image;
@@ -546,7 +520,6 @@ int atacom_snapshot_save(atacom_handle* h, void* d_image, void* stream) {
 }
 int atacom_snapshot_restore(atacom_handle* h, const void* d_image, void* stream) {
     if (!h || !d_image) return fail(ATACOM_E_INVALID, "atacom_snapshot_restore: null argument");
-    if (h->serving) return fail(ATACOM_E_INVALID, "atacom_snapshot_restore: the handle is serving (atacom_server_start): its state lives in the running launch until atacom_server_stop");
     ON_DEVICE(h);
     const size_t B = (size_t)h->cfg.batch, nf = (size_t)h->ops->elem * h->ops->n_planes * B;
     const char* img = (const char*)d_image;
@@ -572,7 +545,6 @@ int atacom_snapshot_restore(atacom_handle* h, const void* d_image, void* stream)
 
 int atacom_get_aux_state(atacom_handle* h, void* d_aux, void* stream) {
     if (!h || !d_aux) return fail(ATACOM_E_INVALID, "atacom_get_aux_state: null argument");
-    if (h->serving) return fail(ATACOM_E_INVALID, "atacom_get_aux_state: the handle is serving (atacom_server_start): its state lives in the running launch until atacom_server_stop");
     if (h->cfg.env_id != ATACOM_ENV_IIWA) return fail(ATACOM_E_INVALID, "atacom_get_aux_state: ATACOM_ENV_IIWA only");
     ON_DEVICE(h);
     atacom::ops_iiwa_dyn(h->cfg.dtype)->get_aux(h->cfg, h->f, d_aux, (hipStream_t)stream);
@@ -582,7 +554,6 @@ int atacom_get_aux_state(atacom_handle* h, void* d_aux, void* stream) {
 
 int atacom_set_aux_state(atacom_handle* h, const void* d_aux, void* stream) {
     if (!h || !d_aux) return fail(ATACOM_E_INVALID, "atacom_set_aux_state: null argument");
-    if (h->serving) return fail(ATACOM_E_INVALID, "atacom_set_aux_state: the handle is serving (atacom_server_start): its state lives in the running launch until atacom_server_stop");
     if (h->cfg.env_id != ATACOM_ENV_IIWA) return fail(ATACOM_E_INVALID, "atacom_set_aux_state: ATACOM_ENV_IIWA only");
     ON_DEVICE(h);
     atacom::ops_iiwa_dyn(h->cfg.dtype)->set_aux(h->cfg, h->f, d_aux, (hipStream_t)stream);
@@ -592,7 +563,6 @@ int atacom_set_aux_state(atacom_handle* h, const void* d_aux, void* stream) {
 
 static int filter_io(atacom_handle* h, void* d_buf, int set, void* stream, const char* who) {
     if (!h || !d_buf) return fail(ATACOM_E_INVALID, std::string(who) + ": null argument");
-    if (h->serving) return fail(ATACOM_E_INVALID, std::string(who) + ": the handle is serving");
     if (h->cfg.env_id != ATACOM_ENV_PLANAR && h->cfg.env_id != ATACOM_ENV_IIWA)
         return fail(ATACOM_E_INVALID, std::string(who) + ": ATACOM_ENV_PLANAR / ATACOM_ENV_IIWA only");
     ON_DEVICE(h);
@@ -605,124 +575,6 @@ int atacom_get_filter_state(atacom_handle* h, void* d_filter, void* stream) {
 }
 int atacom_set_filter_state(atacom_handle* h, const void* d_filter, void* stream) {
     return filter_io(h, const_cast<void*>(d_filter), 1, stream, "atacom_set_filter_state");
-}
-
-// transport 1 of the step server: ONE single-wave kernel per submission on the caller's stream -- it releases step t (the
-// caller's kernels before it in the stream have written the actions) and holds the stream until the step's workgroups have
-// all reported (the caller's kernels after it see the outputs).  t < 0: only the stop flag.
-__global__ void k_server_kick(int* go, unsigned int* done, int t, unsigned int target, long long spin_limit) {
-    if (threadIdx.x != 0) return;
-    __hip_atomic_store(go, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    if (t < 0) return;
-    long long spins = 0;
-    while (__hip_atomic_load(done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < spin_limit)
-        __builtin_amdgcn_s_sleep(1);
-}
-
-// ---- step server: the experiment of VERDICT r3 item 5 (atacom_kernels.h: k_server; results: profiles/r04_step_server.md)
-int atacom_server_start(atacom_handle* h, const void* d_action, void* d_obs, void* d_reward, uint8_t* d_absorbing,
-                        uint8_t* d_last, int32_t max_steps, double timeout_s, int32_t transport) {
-    if (!h) return fail(ATACOM_E_INVALID, "atacom_server_start: null handle");
-    if (h->serving) return fail(ATACOM_E_INVALID, "atacom_server_start: already serving");
-    if (!d_action || !d_obs || !d_reward || !d_absorbing)
-        return fail(ATACOM_E_INVALID, "atacom_server_start: d_action, d_obs, d_reward and d_absorbing are required");
-    if (max_steps <= 0) return fail(ATACOM_E_INVALID, "atacom_server_start: max_steps must be positive");
-    if (transport != 0 && transport != 1) return fail(ATACOM_E_INVALID, "atacom_server_start: transport must be 0 or 1");
-    const atacom_config& c = h->cfg;
-    decltype(atacom::VariantOps::server) launch = nullptr;
-    if (c.dynamics_mode == 0 && !(c.obs_noise || c.obs_delay || c.env_noise)) {
-        if (c.chart_mode == 1) {
-            const atacom::VariantOps* v = atacom::ops_chart(c.env_id, c.dtype);
-            launch = v ? v->server : nullptr;
-        } else {
-            launch = h->ops->server;
-        }
-    }
-    if (!launch)
-        return fail(ATACOM_E_UNSUPPORTED, "atacom_server_start: float32 handles in the kinematic mode without the noise options only");
-    ON_DEVICE(h);
-    // every workgroup of the launch must be resident AT ONCE (they all spin on the same flag) and the caller's own kernels
-    // need room beside them: the launch may take at most half of the compute units (its waves own a SIMD each)
-    int cus = 0, can_wait = 0;
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
-    HIP_TRY(hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, h->device));
-    if (!can_wait && transport == 0)
-        return fail(ATACOM_E_UNSUPPORTED, "atacom_server_start: the device does not support hipStreamWaitValue32");
-    const int lanes = pick_lanes(c, KIND_STEP) >= 4 ? 4 : 1;
-    const int waves = (c.batch * lanes + 63) / 64;
-    if (waves > 2 * cus)
-        return fail(ATACOM_E_UNSUPPORTED, "atacom_server_start: the batch needs more than half of the device's SIMDs (" +
-                                          std::to_string(waves) + " wavefronts, " + std::to_string(4 * cus) + " SIMDs): its "
-                                          "workgroups could not all be resident next to the caller's kernels");
-    if (h->srv_go && h->srv_transport != transport) {               // the flags live in different memory per transport
-        (void)hipFree(h->srv_go); (void)hipFree(h->srv_done);
-        h->srv_go = nullptr; h->srv_done = nullptr;
-    }
-    if (!h->srv_stream) HIP_TRY(hipStreamCreateWithFlags(&h->srv_stream, hipStreamNonBlocking));
-    if (!h->srv_err) HIP_TRY(hipMalloc((void**)&h->srv_err, sizeof(int)));
-    if (!h->srv_go) {
-        if (transport == 0) {
-            HIP_TRY(hipExtMallocWithFlags((void**)&h->srv_go, 8, hipMallocSignalMemory));
-            HIP_TRY(hipExtMallocWithFlags((void**)&h->srv_done, 8, hipMallocSignalMemory));
-        } else {
-            HIP_TRY(hipMalloc((void**)&h->srv_go, 256));
-            HIP_TRY(hipMalloc((void**)&h->srv_done, 256));
-        }
-    }
-    h->srv_transport = transport;
-    HIP_TRY(hipDeviceSynchronize());              // everything queued on the handle so far has landed in its state buffers
-    HIP_TRY(hipMemset(h->srv_go, 0, 8));
-    HIP_TRY(hipMemset(h->srv_done, 0, 8));
-    HIP_TRY(hipMemset(h->srv_err, 0, sizeof(int)));
-    HIP_TRY(hipDeviceSynchronize());
-    // one poll = s_sleep 8 (~0.25 us) + a system-scope load (~1 us): the limit is a time-out in polls
-    const long long spin_limit = (long long)((timeout_s > 0 ? timeout_s : 5.0) * 8e5) + 1;
-    h->srv_spin = spin_limit;
-    h->srv_blocks = launch(c, lanes, max_steps, h->f, h->ip, d_action, d_obs, d_reward, d_absorbing, d_last, h->srv_go,
-                           h->srv_done, h->srv_err, spin_limit, h->srv_stream);
-    HIP_TRY(hipGetLastError());
-    h->srv_t = 0;
-    h->srv_max = max_steps;
-    h->serving = true;
-    return ATACOM_OK;
-}
-
-int atacom_server_submit(atacom_handle* h, void* stream) {
-    if (!h || !h->serving) return fail(ATACOM_E_INVALID, "atacom_server_submit: the handle is not serving");
-    if (h->srv_t >= h->srv_max)
-        return fail(ATACOM_E_INVALID, "atacom_server_submit: max_steps of atacom_server_start are used up");
-    ON_DEVICE(h);
-    h->srv_t += 1;
-    const uint32_t target = (uint32_t)h->srv_blocks * (uint32_t)h->srv_t;
-    if (h->srv_transport == 0) {
-        HIP_TRY(hipStreamWriteValue32((hipStream_t)stream, h->srv_go, (uint32_t)h->srv_t, 0));
-        HIP_TRY(hipStreamWaitValue32((hipStream_t)stream, h->srv_done, target, hipStreamWaitValueGte, 0xFFFFFFFFu));
-    } else {
-        hipLaunchKernelGGL(k_server_kick, dim3(1), dim3(64), 0, (hipStream_t)stream, h->srv_go, h->srv_done, h->srv_t, target,
-                           h->srv_spin * 4);
-        HIP_TRY(hipGetLastError());
-    }
-    return ATACOM_OK;
-}
-
-int atacom_server_stop(atacom_handle* h, void* stream) {
-    if (!h || !h->serving) return fail(ATACOM_E_INVALID, "atacom_server_stop: the handle is not serving");
-    ON_DEVICE(h);
-    h->serving = false;
-    // The stop flag travels on the CALLER's stream, the one the submissions came through.  (First version: a third stream of
-    // the library's own.  HIP multiplexes its streams onto a few hardware queues; in a process with several streams that
-    // third stream shared the SERVER's queue, its write sat behind the running launch, and stop waited for the launch's own
-    // time-out -- measured, profiles/r04_step_server.md.)
-    if (h->srv_t < h->srv_max) {                  // (a launch that served all its steps has ended by itself)
-        if (h->srv_transport == 0) HIP_TRY(hipStreamWriteValue32((hipStream_t)stream, h->srv_go, 0xFFFFFFFFu, 0));
-        else hipLaunchKernelGGL(k_server_kick, dim3(1), dim3(64), 0, (hipStream_t)stream, h->srv_go, h->srv_done, -1, 0u, 0ll);
-    }
-    HIP_TRY(hipStreamSynchronize(h->srv_stream));
-    int err = 0;
-    HIP_TRY(hipMemcpy(&err, h->srv_err, sizeof(int), hipMemcpyDeviceToHost));
-    if (err) return fail(ATACOM_E_HIP, "atacom_server_stop: the launch had timed out waiting for a submission (its state was "
-                                       "written back at that point)");
-    return ATACOM_OK;
 }
 
 int atacom_inverse_dynamics(int32_t dtype, int32_t n, const void* d_q, const void* d_dq, const void* d_ddq, void* d_tau,

@@ -90,13 +90,8 @@ __device__ __forceinline__ void constraint_fun(Circle, const Params<T>&, const T
 }
 
 // ---------------------------------------------------------------------------------------- planar
-// (fp contract off in the planar kinematics: the link products cx, sy are summed AND used on their own, and whether the
-// optimiser fuses such a sum into an fma depends on the kernel around it -- the step server's instantiation differed from
-// atacom_step's by one ulp in three values after two steps.  Every multiply-add that is meant to be fused is an explicit
-// num<T>::fma; with contraction off here all instantiations of the planar task agree bit for bit.)
 template <typename T>
 __device__ __forceinline__ void planar_fk(const Params<T>& P, const T (&q)[3], T (&cx)[3], T (&sy)[3]) {
-#pragma clang fp contract(off)
     T th = T(0);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -110,7 +105,6 @@ __device__ __forceinline__ void planar_fk(const Params<T>& P, const T (&q)[3], T
 template <typename T>
 __device__ __forceinline__ void constraint_terms(Planar, const Params<T>& P, const T (&q)[3], const T (&dq)[3],
                                                  T (&fun)[6], T (&J)[6][3], T (&bst)[6]) {
-#pragma clang fp contract(off)
     T cx[3], sy[3];
     planar_fk(P, q, cx, sy);
     const T xw = (cx[0] + cx[1] + cx[2]) + P.base_x;
@@ -154,7 +148,6 @@ __device__ __forceinline__ void constraint_terms(Planar, const Params<T>& P, con
 }
 template <typename T>
 __device__ __forceinline__ void constraint_fun(Planar, const Params<T>& P, const T (&q)[3], T (&fun)[6], T (&mxy)[2]) {
-#pragma clang fp contract(off)
     T cx[3], sy[3];
     planar_fk(P, q, cx, sy);
     const T xw = (cx[0] + cx[1] + cx[2]) + P.base_x;

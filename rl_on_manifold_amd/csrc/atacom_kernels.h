@@ -991,86 +991,6 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
     if constexpr (DYN) store_aux<T, E>(f, B, b, st);
 }
 
-// ------------------------------------------------------------------ step server (an experiment)
-// A PERSISTENT launch that keeps every environment's state in registers -- as k_rollout does -- but takes the action of
-// each step from the caller while it runs: per step a workgroup waits for the device flag `go` to pass the step's number
-// (written from the caller's stream, hipStreamWriteValue32), reads its actions, steps, writes observation / reward / flags
-// and adds one to the counter `done`, on which the caller's stream waits (hipStreamWaitValue32).  What it removes is the
-// ~3.4 us per atacom_step launch that are not instructions (dispatch skew, first loads after the kernel-boundary cache
-// invalidate, store tail: DESIGN.md section 6); what it adds is the flag round trip.  Visibility follows the inter-workgroup
-// rule of the CDNA guide: agent-scope acquire after the flag is seen (drops the L1 lines of the action buffer, which are
-// re-written at the same addresses every step), agent-scope release before the counter is bumped.
-// go < 0: stop.  A flag that does not move for `spin_limit` polls ends the launch as well (err = 1, `done` jumps so that
-// no stream stays blocked on it): a forgotten submit must not hang the device.
-template <typename T, typename E, int LANES, bool HOLD, int CHART = 0>
-__global__ void __launch_bounds__(BLOCK<LANES>) k_server(const Params<T> P, int max_steps, T* __restrict__ f,
-                                                 int* __restrict__ ip, const T* action, T* obs, T* reward,
-                                                 uint8_t* absorbing, uint8_t* last, int* go, unsigned int* done, int* err,
-                                                 long long spin_limit) {
-    using L = Planes<E>;
-    __shared__ int sh_go;
-    const int B = P.batch;
-    const int gt = blockIdx.x * BLOCK<LANES> + threadIdx.x;
-    const int b = gt / LANES;
-    const int lq = gt % LANES;
-    if (b >= B) return;                               // (whole waves only -- the host rounds the launch to full workgroups)
-    const EnvRef<T, false> ref{f, ip, B, b, true};
-    EnvState<T, E> st;
-    load_state<T, E>(f, ip, B, b, st);
-    T ssum = T(0), scmax = pl<E>(f, L::SCMAX, B, b), sdq = pl<E>(f, L::SDQMAX, B, b);
-    int served = 0;
-#pragma unroll 1
-    for (int t = 0; t < max_steps; ++t) {
-        if (threadIdx.x == 0) {
-            int v = 0;
-            long long spins = 0;
-            do {
-                v = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (v > t || v < 0) break;
-                __builtin_amdgcn_s_sleep(8);
-            } while (++spins < spin_limit);
-            sh_go = v;
-        }
-        __syncthreads();
-        const int v = sh_go;
-        __syncthreads();                              // (sh_go is rewritten by thread 0 in the next iteration)
-        if (v < 0) break;
-        if (v <= t) {                                 // timed out
-            if (threadIdx.x == 0) {
-                atomicExch(err, 1);
-                __hip_atomic_fetch_max(done, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            break;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        T act[E::NK];
-#pragma unroll
-        for (int k = 0; k < E::NK; ++k) act[k] = action[(size_t)b * E::NK + k];
-        StepOut<T> out;
-        env_step<T, E, LANES, HOLD, false, true, CHART>(P, st, act, out, lq, ref);
-        if (lq == 0) {
-            write_obs<T, E>(P, st, obs + (size_t)b * E::OBS, ref);
-            reward[b] = out.reward;
-            absorbing[b] = out.absorbing ? 1 : 0;
-            if (last) last[b] = out.last ? 1 : 0;
-        }
-        ssum += out.log_avg;
-        scmax = num<T>::max(scmax, out.log_max);
-        sdq = num<T>::max(sdq, out.log_dq);
-        ++served;
-        if (P.auto_reset && out.last) reset_env<T, E>(P, ref, st);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (lq != 0) return;
-    pl<E>(f, L::SSUM, B, b) += ssum;
-    pl<E>(f, L::SCMAX, B, b) = scmax;
-    pl<E>(f, L::SDQMAX, B, b) = sdq;
-    pli(ip, L::I_CNT, b) += served;
-    store_state<T, E>(f, ip, B, b, st);
-}
-
 // Row N2: rollout with the policy MLP evaluated in the kernel (atacom_policy.h).  d_actions_out receives the action
 // the policy drew (mean + std * noise, before the env's clip to [-1, 1]).
 // float: the network runs on the matrix cores (mlp_forward_mfma), one wavefront = 1 (quad mapping) or 4 (lane mapping)

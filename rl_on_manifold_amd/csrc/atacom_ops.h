@@ -34,9 +34,6 @@ struct EnvOps {
                   hipStream_t s);
     // obs_delay: the low-pass state [batch, 3 + nq] (planar / iiwa; no-op otherwise); set != 0 writes it
     void (*filter_io)(const atacom_config&, void* f, void* buf, int set, hipStream_t s);
-    // step server of the default variant (see VariantOps::server); nullptr for the float64 build
-    int (*server)(const atacom_config&, int lanes, int max_steps, void* f, int* ip, const void* act, void* obs, void* rew,
-                  uint8_t* ab, uint8_t* last, int* go, unsigned int* done, int* err, long long spin_limit, hipStream_t s);
 };
 
 // The three stepping entry points of a kernel variant other than the default one (atacom_ops_impl.h: Variant)
@@ -51,10 +48,6 @@ struct VariantOps {
     // the canonical chart as a primitive: A [n, c, q], s [n, g], y [n, c], alpha [n, k] -> mu [n, q + g]
     void (*chart_mu)(int n, const void* A, const void* sl, const void* y, const void* alpha, double tol, void* mu,
                      hipStream_t s);
-    // step server (float32, kinematic mode, options off; nullptr otherwise): launches the persistent kernel, returns the
-    // number of workgroups (= what one served step adds to the `done` counter)
-    int (*server)(const atacom_config&, int lanes, int max_steps, void* f, int* ip, const void* act, void* obs, void* rew,
-                  uint8_t* ab, uint8_t* last, int* go, unsigned int* done, int* err, long long spin_limit, hipStream_t s);
 };
 // canonical-chart kernels (cfg.chart_mode = 1) of circle / planar / iiwa: atacom_chart.hip, atacom_chart_iiwa.hip
 const VariantOps* ops_chart(int env_id, int dtype);

@@ -142,29 +142,8 @@ struct Variant {
             hipLaunchKernelGGL((k_chart<T, E>), dim3(nblk(n, WAVE)), dim3(WAVE), 0, s, n, (const T*)A, (const T*)sl,
                                (const T*)y, (const T*)alpha, (T)tol, (T*)mu);
     }
-    static constexpr bool SERVER = std::is_same<T, float>::value && !DYN && !NOISE;
-    static int server(const atacom_config& c, int lanes, int max_steps, void* f, int* ip, const void* act, void* obs,
-                      void* rew, uint8_t* ab, uint8_t* last, int* go, unsigned int* done, int* err, long long spin_limit,
-                      hipStream_t s) {
-        int blocks = 0;
-        if constexpr (SERVER) {
-            auto launch = [&](auto lc, auto hc) {
-                constexpr int LANES = decltype(lc)::value;
-                constexpr bool HOLD = decltype(hc)::value;
-                blocks = nblk(c.batch * LANES, BLOCK<LANES>);
-                hipLaunchKernelGGL((k_server<T, E, LANES, HOLD, CHART>), dim3(blocks), dim3(BLOCK<LANES>), 0, s,
-                                   make_params<T>(c), max_steps, (T*)f, ip, (const T*)act, (T*)obs, (T*)rew, ab, last, go, done,
-                                   err, spin_limit);
-            };
-            // two mappings: the quad (half of the chip stays free for the caller's kernels at 8192 environments) and one
-            // environment per lane
-            if (lanes >= 4) { if (c.hold_q) launch(std::integral_constant<int, 4>{}, std::true_type{}); else launch(std::integral_constant<int, 4>{}, std::false_type{}); }
-            else { if (c.hold_q) launch(std::integral_constant<int, 1>{}, std::true_type{}); else launch(std::integral_constant<int, 1>{}, std::false_type{}); }
-        }
-        return blocks;
-    }
     static const VariantOps* table() {
-        static const VariantOps ops = {&step, &rollout, &rollout_mlp, &chart_mu, SERVER ? &server : nullptr};
+        static const VariantOps ops = {&step, &rollout, &rollout_mlp, &chart_mu};
         return &ops;
     }
 };
@@ -223,8 +202,7 @@ struct Ops {
     static const EnvOps* table() {
         static const EnvOps ops = {L::VALUES_PER_ENV, L::ICOUNT, L::STATE_DIM, L::INIT_DIM, E::OBS, E::NQ, E::NF, E::NG, E::NK,
                                    sizeof(T), &V::step, &V::rollout, &V::rollout_mlp, &reset, &fill_init, &clear_stats, &stats,
-                                   &get_state, &set_state, &nullspace, &terms, &filter_io,
-                                   V::SERVER ? &V::server : nullptr};
+                                   &get_state, &set_state, &nullspace, &terms, &filter_io};
         return &ops;
     }
 };

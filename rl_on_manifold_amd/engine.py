@@ -411,23 +411,6 @@ class BatchedAtacomEnv:
         a = self._as_dev(fv, (self.batch, 3 + self.dims['q']))
         _lib.check(self._lib.atacom_set_filter_state(self._h, _ptr(a), self._stream()))
 
-    def serve(self, actions, max_steps, timeout_s=5.0, transport='kernel'):
-        """Step server (an experiment, include/atacom_hip.h: atacom_server_*): ONE persistent launch keeps the state of every
-        environment in registers and serves one env step per `submit()` from fixed buffers -- `actions` [B, k] (the caller
-        writes each step's actions into THIS tensor on the current stream) in, `.obs` / `.reward` / `.absorbing` / `.last`
-        out.  No host synchronisation per step: submit() enqueues, on the current stream, what releases the step and holds the
-        stream until it is done -- transport 'kernel': one single-wave kernel; 'stream_ops': hipStreamWriteValue32 +
-        hipStreamWaitValue32 (measured: ~170 us per pair on this stack, profiles/r04_step_server.md).
-
-            with env.serve(act_buf, max_steps=120) as srv:
-                for t in range(120):
-                    act_buf.copy_(policy(srv.obs))       # any torch kernels on the current stream
-                    srv.submit()                          # kernels enqueued after this see the step's outputs
-
-        Do not call torch.cuda.synchronize() / empty_cache() inside the block (they wait for the launch, which waits for
-        submissions, until `timeout_s` passes): synchronise the current STREAM instead."""
-        return StepServer(self, actions, max_steps, timeout_s, transport)
-
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
             self._lib.atacom_destroy(self._h)
@@ -438,41 +421,6 @@ class BatchedAtacomEnv:
             self.close()
         except Exception:  # noqa: BLE001
             pass
-
-
-class StepServer:
-    """See BatchedAtacomEnv.serve."""
-
-    def __init__(self, env, actions, max_steps, timeout_s=5.0, transport='kernel'):
-        B, k, D = env.batch, env.dims['null'], env.obs_dim
-        env._check_io(actions, (B, k), env.dtype, 'actions')
-        self.env, self.actions = env, actions
-        self.obs = torch.empty((B, D), device=env.device, dtype=env.dtype)
-        self.reward = torch.empty((B,), device=env.device, dtype=env.dtype)
-        self.absorbing = torch.empty((B,), device=env.device, dtype=torch.uint8)
-        self.last = torch.empty((B,), device=env.device, dtype=torch.uint8)
-        self.obs.copy_(env.reset(mask=torch.zeros(B, dtype=torch.uint8, device=env.device)))     # the current observation
-        torch.cuda.current_stream(env.device).synchronize()
-        _lib.check(env._lib.atacom_server_start(env._h, _ptr(actions), _ptr(self.obs), _ptr(self.reward), _ptr(self.absorbing),
-                                                _ptr(self.last), int(max_steps), float(timeout_s),
-                                                {'stream_ops': 0, 'kernel': 1}[transport]))
-        self.active = True
-
-    def submit(self):
-        _lib.check(self.env._lib.atacom_server_submit(self.env._h, self.env._stream()))
-
-    def stop(self):
-        if self.active:
-            self.active = False
-            torch.cuda.current_stream(self.env.device).synchronize()      # the last step's outputs have landed
-            _lib.check(self.env._lib.atacom_server_stop(self.env._h, self.env._stream()))
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        self.stop()
-        return False
 
 
 class GraphedRollout:

@@ -57,18 +57,15 @@ def test_no_promoted_arrays_and_no_scratch_in_the_production_kernels(tmp_path):
     ks = _kernels(str(tmp_path))
     assert len(ks) > 400                                     # 3 tasks + 2 circle baselines, 2 dtypes, 4 mappings, 2 charts, ...
     assert any(k[0].startswith('k_step<float, Iiwa, 4, true, false, 0, false>') for k in ks), [k[0] for k in ks][:5]
-    # static LDS: only the two-stage statistics reduction declares any, and the step server its 4-byte flag slot (the
-    # policy kernels' LDS is dynamic)
+    # static LDS: only the two-stage statistics reduction declares any (the policy kernels' LDS is dynamic)
     lds = [k for k in ks if k[1] != 0]
-    assert lds and all(k[0].startswith('k_stats<') or (k[0].startswith('k_server<') and k[1] <= 16) for k in lds), lds
+    assert lds and all(k[0].startswith('k_stats<') for k in lds), lds
     # float32, kinematic mode (DYN = false), every task, mapping and chart: the single-step kernels never touch scratch,
     # and neither do the T-step kernels of the lane-group mappings
     def args(name):
         return [a.strip() for a in name[name.index('<') + 1:name.rindex('>')].split(',')]
     bad, n_noise = [], 0
     for name, _, scratch, *_ in ks:
-        if name.startswith('k_server<float') and scratch and int(args(name)[2]) > 1:
-            bad.append((name, scratch))                      # the step server's quad kernels: no scratch either
         if not name.startswith(('k_step<float', 'k_rollout<float')):
             continue
         a = args(name)                                       # T, E, LANES, HOLD, DYN, CHART, NOISE
