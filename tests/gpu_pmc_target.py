@@ -1,5 +1,5 @@
 """Tiny target for rocprofv3 --pmc passes: a few atacom_step launches.
-    python tests/gpu_pmc_target.py LANES [BATCH] [ENV] [CHART]        (defaults: 0 8192 iiwa reference)"""
+    python tests/gpu_pmc_target.py LANES [BATCH] [ENV] [CHART] [DYNAMICS]        (defaults: 0 8192 iiwa reference kinematic)"""
 import sys
 import torch
 sys.path.insert(0, '.')
@@ -8,7 +8,8 @@ lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 name = sys.argv[3] if len(sys.argv) > 3 else 'iiwa'
 chart = sys.argv[4] if len(sys.argv) > 4 else 'reference'
-env = BatchedAtacomEnv(name, B, dtype=torch.float32, auto_reset=True, lanes_per_env=lanes, chart_mode=chart)
+dyn = sys.argv[5] if len(sys.argv) > 5 else 'kinematic'
+env = BatchedAtacomEnv(name, B, dtype=torch.float32, auto_reset=True, lanes_per_env=lanes, chart_mode=chart, dynamics_mode=dyn)
 gen = torch.Generator(device='cuda:0'); gen.manual_seed(0)
 st = env.get_state()
 nq, ng, k = env.dims['q'], env.dims['g'], env.dims['null']

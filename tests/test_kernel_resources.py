@@ -70,7 +70,11 @@ def test_no_promoted_arrays_and_no_scratch_in_the_production_kernels(tmp_path):
             continue
         a = args(name)                                       # T, E, LANES, HOLD, DYN, CHART, NOISE
         if a[4] == 'true':
-            continue                                         # rigid-body mode: scratch allowed (opt-in)
+            # rigid-body mode (opt-in): the dynamics do not fit next to the held solver state -- bounded, not
+            # banned: the quad step kernels of the default chart spill at most 64 bytes per lane (measured 32 - 48), nothing beyond 700 anywhere
+            if scratch > (64 if (name.startswith('k_step<') and a[2] == '4' and a[5] == '0') else 700):
+                bad.append((name, scratch))
+            continue
         noise = a[6] == 'true'                               # the kernels with the domain-randomisation options compiled in
         n_noise += noise
         if noise and a[3] == 'false' and name.startswith('k_rollout<'):
