@@ -20,6 +20,13 @@
 namespace atacom {
 
 constexpr int WAVE = 64;
+#ifndef ATACOM_CHART_FORM3_PLANAR
+#define ATACOM_CHART_FORM3_PLANAR 0
+#endif
+// rigid-body kernels: park the held solver state in LDS across the dynamics (env_step); -DATACOM_DYN_PARK=0: the A/B build
+#ifndef ATACOM_DYN_PARK
+#define ATACOM_DYN_PARK 1
+#endif
 // threads per workgroup of the step / rollout kernels: the quad mapping runs 2.7 % faster with four waves per
 // workgroup (one per SIMD of a CU, sharing the instruction cache), the lane mapping with one (measured, profiles/)
 #ifndef ATACOM_BLOCK_GROUP
@@ -399,7 +406,9 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
 // (and bitwise identically) by the four lanes; `lq` is the lane's index in its quad.
 // CHART = 1: the opt-in canonical chart (atacom_chart.h) instead of the reference's LAPACK-basis + rref(tol) chart; with
 // LANES > 1 its square-root recursion is distributed over the lanes of the group (one vector per lane with 8 lanes).
-template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, bool HOIST_G0 = true, int CHART = 0, typename Ref>
+// THREADS: threads per workgroup of the calling kernel (sizes the LDS slice the rigid-body mode parks its solver state in)
+template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, bool HOIST_G0 = true, int CHART = 0,
+          int THREADS = BLOCK<LANES>, typename Ref>
 __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st, const T (&act)[E::NK],
                                          StepOut<T>& out, const int lq, const Ref& ref) {
     using L = Planes<E>;
@@ -454,7 +463,13 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                                // slot (c-1) / LANES; column 0 is replicated and read from A directly, atacom_quad.h)
     T tlo[NQ], tup[NQ];         // acc_truncation bounds (atacom.py:117-121): functions of the controller's dq only
     // CANON, LANES > 1 (third form, atacom_chart_group.h): the lane's own columns / rows of A, built with A
-    constexpr bool CANON3 = CANON && LANES > 1 && (ATACOM_CHART_FORM == 3);
+    // (iiwa only: on the planar task the third form is faster -- 10.8 against 13.6 us per step at 8192 environments -- but its
+    // float32 soak lost accuracy where a soft row's weight 1 / s^2 crosses 1 / tol^2 and a joint's pivot sits at the chart's
+    // threshold: 64 samples of 295 k beyond the quick sensitivity bound against 1 for the second form, 7 unexplained by the
+    // deep probe; the float64 instantiation is exact and the iiwa soaks of the two forms agree (9 against 8 samples).  Cause
+    // not found -- the two forms are the same arithmetic on paper, and the metric's rounding was ruled out by an A/B build
+    // (profiles/r04_chart_form3_planar.md) -- so the planar task keeps the second form.)
+    constexpr bool CANON3 = CANON && LANES > 1 && (ATACOM_CHART_FORM == 3) && (E::ID == 2 || ATACOM_CHART_FORM3_PLANAR);
     [[maybe_unused]] ChartPre<T, E, LGC> cpre;
     auto prepare = [&](int sub) {
 #pragma unroll
@@ -659,7 +674,60 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 st.dq[i] = num<T>::fma(acc, P.dt_base, st.dq[i]);
             }
         } else {
-            if constexpr (DYN && E::ID == 2) rigid_body_substep<T, E>(P, st, ddq);      // row N4: ddq <- forward dynamics
+            if constexpr (DYN && E::ID == 2) {
+                // row N4: ddq <- forward dynamics.  What the solver holds over the sub-steps -- the lane's columns of K J, its
+                // replicated column 0, the slack-independent right-hand side, the truncation bounds: 84 values -- is PARKED
+                // IN LDS across the rigid-body sub-step (float, reference chart): the nine-body chain, the Newton-Euler pass
+                // and the mass-matrix rows need ~300 registers of their own, and next to the held state the kernels spilled
+                // to scratch (32 - 200 bytes per lane through global memory, per sub-step).  21 ds_write_b128 + 21
+                // ds_read_b128 per sub-step instead; every lane owns its slice, no barrier.
+                constexpr bool PARK = std::is_same<T, float>::value && !CANON && E::MODE == 0 && ATACOM_DYN_PARK &&
+                                      (LANES > 1 || THREADS == BLOCK<LANES>);      // (the lane-mapped policy kernel's own 100 KB
+                                                                                   // of LDS leave no room: it keeps its scratch)
+                if constexpr (PARK) {
+                    constexpr int NV = (LANES > 1 ? NC * SQ + NC : NC * NQ) + NC + 2 * NQ, NG4 = (NV + 3) / 4;
+                    __shared__ float4 parked[NG4 * THREADS];
+                    T pk[NG4 * 4];
+                    int k = 0;
+                    auto walk = [&](auto&& f) {                 // the same order on the way in and out
+                        k = 0;
+                        if constexpr (LANES > 1) {
+#pragma unroll
+                            for (int r = 0; r < NC; ++r) {
+#pragma unroll
+                                for (int sl = 0; sl < SQ; ++sl) f(Aq[r][sl]);
+                                f(A[r][0]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < NC; ++r)
+#pragma unroll
+                                for (int i = 0; i < NQ; ++i) f(A[r][i]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < NC; ++r) f(yb[r]);
+#pragma unroll
+                        for (int i = 0; i < NQ; ++i) { f(tlo[i]); f(tup[i]); }
+                    };
+#pragma unroll
+                    for (int i = 0; i < NG4 * 4; ++i) pk[i] = T(0);
+                    walk([&](T& v) { pk[k++] = v; });
+#pragma unroll
+                    for (int g4 = 0; g4 < NG4; ++g4)
+                        parked[g4 * THREADS + threadIdx.x] = make_float4(pk[4 * g4], pk[4 * g4 + 1], pk[4 * g4 + 2], pk[4 * g4 + 3]);
+                    asm volatile("" ::: "memory");
+                    rigid_body_substep<T, E>(P, st, ddq);
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int g4 = 0; g4 < NG4; ++g4) {
+                        const float4 v = parked[g4 * THREADS + threadIdx.x];
+                        pk[4 * g4] = v.x; pk[4 * g4 + 1] = v.y; pk[4 * g4 + 2] = v.z; pk[4 * g4 + 3] = v.w;
+                    }
+                    walk([&](T& v) { v = pk[k++]; });
+                } else {
+                    rigid_body_substep<T, E>(P, st, ddq);
+                }
+            }
             // dynamics model of this build: ID o FD = identity (or the rigid-body mode above), semi-implicit
             // Euler, velocity clamp at 1.5 x limit (iiwa_hit_atacom.py:48-50)
 #pragma unroll
@@ -1095,7 +1163,7 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
         // (one environment per lane with the network's four GEMM blocks live is the one kernel at the edge of the register
         // file: with the G(0) hoist its spills move INTO the sub-step loop -- 59.6 -> 79.5 us per step, measured -- so it
         // keeps the un-hoisted solver)
-        env_step<T, E, LANES, HOLD, DYN, (LANES > 1), CHART>(P, st, act, out, lq, ref);
+        env_step<T, E, LANES, HOLD, DYN, (LANES > 1), CHART, THREADS>(P, st, act, out, lq, ref);
         if (lq == 0 && valid) {
             if (rec) {
                 write_obs<T, E>(P, st, rrow + R::NOBS, ref);

@@ -204,7 +204,7 @@ def test_env_step_canonical_chart(name, dt, lanes):
         print('%s: reference-chart parity on %.1f %% of the samples (the rest: the reference takes its tolerance branch)'
               % (name, 100 * clear.mean()))
     else:
-        print(rec.finish('%s canonical, lanes %d' % (name, lanes), max_vacuous={'circle': 0.0, 'planar': 0.01, 'iiwa': 0.35}[name]))
+        print(rec.finish('%s canonical, lanes %d' % (name, lanes), max_vacuous={'circle': 0.0, 'planar': 0.01, 'iiwa': 0.10}[name]))      # measured 6.6 % (round 4)
 
 
 @pytest.mark.parametrize('name', ['planar', 'iiwa'])

@@ -5,8 +5,8 @@ constructor kwargs of iiwa_hit_atacom.py:11-13 / atacom_air_hockey.py:12-14, all
 The reference draws from numpy's global, unseeded generator, so only the distribution can match it; the engine draws from
 a counter-based generator hash(seed, env, episode, step, draw) that the oracle restates, so HIP = oracle DRAW FOR DRAW
 (float64 1e-8, float32 by the sensitivity rule, every kernel mapping), and the moments are checked against the
-reference's formulas.  With the options off the kernels are the ones every other test runs (the branches are
-launch-uniform and keep no state in registers: profiles/r04_ab_noise_options.log)."""
+reference's formulas.  The options are a compile-time parameter of the stepping kernels (atacom_noise_*.hip): with them off
+the kernels are the ones every other test runs, byte for byte."""
 import dataclasses
 
 import numpy as np
@@ -104,7 +104,7 @@ def _teacher_forced(name, dt, lanes, opts, B=256, T=10, chart='reference', hold_
             o.reset(last)
     if dt == 'f32':
         print(rec.finish('%s noise %s lanes %d' % (name, sorted(k for k, v in opts.items() if v), lanes),
-                         max_vacuous=0.45 if name == 'iiwa' else 0.02))
+                         max_vacuous=0.25 if name == 'iiwa' else 0.02))       # measured 16.5 % (iiwa states around the reset pose)
     return worst
 
 
