@@ -63,8 +63,8 @@ typedef struct atacom_config {
                             terminal observation, the next call starts from the reset state */
     int32_t lanes_per_env; /* kernel mapping: 1 = one env per lane, 2 = one env per lane pair, 4 = one env per DPP
                               quad, 8 = one env per 8 lanes (null-space solve split by column over the 2 / 4 / 8
-                              lanes), 0 = let the library choose per env / batch / kernel (iiwa: 8 up to 4096
-                              envs -- 8192 for the T-step kernels --, 4 up to 16384, 2 up to 32768, 1 beyond).
+                              lanes), 0 = let the library choose per env / batch / kernel (iiwa: 8 up to 8192
+                              envs, 4 up to 16384, 2 up to 32768, 1 beyond).
                               Results are the same algorithm either way (summation order differs). */
     double dt;           /* time_step */
     double rref_tol;     /* 0.05, atacom.py:128 */

@@ -95,8 +95,12 @@ int pick_lanes_raw(const atacom_config& c, int kind) {
         return 1;
     }
     if (c.env_id == ATACOM_ENV_IIWA) {
-        const int upto8 = (kind == KIND_ROLLOUT) ? 8192 : 4096;
-        return c.batch <= upto8 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));
+        // Round 4: single steps take the 8-lane mapping up to 8192 environments as well.  Rounds 2 / 3 had measured a tie with
+        // the quad there (27.2 us both, mean of nine boxes, per box from -5 % to +4.5 %) and kept the quad; on the round-4
+        // boxes the 8-lane kernel is 7 % faster every time -- bench workload 24.9 against 26.8 us (three interleaved runs),
+        // constraint-active states 25.9 against 27.8 (two more boxes): profiles/r04_ab_lanes_bench.log, r04_ab_noise_kernels.log
+        (void)kind;
+        return c.batch <= 8192 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));
     }
     if (c.env_id == ATACOM_ENV_PLANAR)
         return c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1);

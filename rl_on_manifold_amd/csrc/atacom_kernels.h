@@ -682,27 +682,22 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 // to scratch (32 - 200 bytes per lane through global memory, per sub-step).  21 ds_write_b128 + 21
                 // ds_read_b128 per sub-step instead; every lane owns its slice, no barrier.
                 constexpr bool PARK = std::is_same<T, float>::value && !CANON && E::MODE == 0 && ATACOM_DYN_PARK &&
-                                      (LANES > 1 || THREADS == BLOCK<LANES>);      // (the lane-mapped policy kernel's own 100 KB
-                                                                                   // of LDS leave no room: it keeps its scratch)
+                                      LANES > 1;       // (one environment per lane: measured SLOWER with the parking, 73.9 ->
+                                                       // 90.7 us per step at 8192 environments -- those kernels still spill and pay
+                                                       // the LDS traffic on top; and the lane-mapped policy kernel's own 100 KB of
+                                                       // LDS would leave no room)
                 if constexpr (PARK) {
-                    constexpr int NV = (LANES > 1 ? NC * SQ + NC : NC * NQ) + NC + 2 * NQ, NG4 = (NV + 3) / 4;
+                    constexpr int NV = NC * SQ + NC + NC + 2 * NQ, NG4 = (NV + 3) / 4;
                     __shared__ float4 parked[NG4 * THREADS];
                     T pk[NG4 * 4];
                     int k = 0;
                     auto walk = [&](auto&& f) {                 // the same order on the way in and out
                         k = 0;
-                        if constexpr (LANES > 1) {
 #pragma unroll
-                            for (int r = 0; r < NC; ++r) {
+                        for (int r = 0; r < NC; ++r) {
 #pragma unroll
-                                for (int sl = 0; sl < SQ; ++sl) f(Aq[r][sl]);
-                                f(A[r][0]);
-                            }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < NC; ++r)
-#pragma unroll
-                                for (int i = 0; i < NQ; ++i) f(A[r][i]);
+                            for (int sl = 0; sl < SQ; ++sl) f(Aq[r][sl]);
+                            f(A[r][0]);
                         }
 #pragma unroll
                         for (int r = 0; r < NC; ++r) f(yb[r]);

@@ -844,12 +844,12 @@ def test_host_side_error_paths_and_multiple_handles():
     with pytest.raises(AtacomError):
         BatchedAtacomEnv('planar', 4, lanes_per_env=3)
     # the mapping the library picks for lanes_per_env = 0 (atacom_capi.cpp: pick_lanes), and an explicit request is kept
-    for name, B, lanes in (('iiwa', 4096, 8), ('iiwa', 8192, 4), ('iiwa', 16384, 4), ('iiwa', 32768, 2), ('iiwa', 65536, 1),
+    for name, B, lanes in (('iiwa', 4096, 8), ('iiwa', 8192, 8), ('iiwa', 16384, 4), ('iiwa', 32768, 2), ('iiwa', 65536, 1),
                            ('planar', 8192, 4), ('planar', 65536, 1), ('circle', 4096, 1)):
         assert BatchedAtacomEnv(name, B, device=DEV).lanes_per_env == lanes, (name, B)
     assert BatchedAtacomEnv('iiwa', 8192, device=DEV, lanes_per_env=8).lanes_per_env == 8
-    e = BatchedAtacomEnv('iiwa', 8192, device=DEV)            # the T-step kernels keep 8 lanes up to 8192 environments
-    assert (e.lanes_per_env, e.rollout_lanes_per_env) == (4, 8)
+    e = BatchedAtacomEnv('iiwa', 8192, device=DEV)            # 8 lanes up to 8192 environments, single steps and T-step kernels
+    assert (e.lanes_per_env, e.rollout_lanes_per_env) == (8, 8)
     e = BatchedAtacomEnv('iiwa', 16384, device=DEV)
     assert (e.lanes_per_env, e.rollout_lanes_per_env) == (4, 4)
     assert BatchedAtacomEnv('iiwa', 64, device=DEV, dtype=torch.float64).lanes_per_env == 1

@@ -68,15 +68,12 @@ def test_no_promoted_arrays_and_no_scratch_in_the_production_kernels(tmp_path):
             return False
         a = args(name)
         dyn, chart = (a[4], a[5]) if not name.startswith('k_rollout_mlp<') else (a[5], a[6])
-        if name.startswith('k_rollout_mlp<') and a[2] == '1':
-            return False                                     # (its own 100 KB of weights and staging leave no room: it spills)
-        return dyn == 'true' and chart == '0'
+        return dyn == 'true' and chart == '0' and a[2] != '1'    # (one environment per lane: measured slower with it, not parked)
     lds = [k for k in ks if k[1] != 0]
     assert lds and all(k[0].startswith('k_stats<') or parked(k[0]) for k in lds), [k for k in lds if not parked(k[0])][:5]
     for k in lds:
         if parked(k[0]):
-            lane = args(k[0])[2] == '1'
-            assert k[1] == (24 * 16 * 64 if lane else 21 * 16 * 256), k      # 96 values (full K J) per lane / 84 in a lane group
+            assert k[1] == 21 * 16 * 256, k                  # 84 values per lane, 256 threads per workgroup
     # float32, kinematic mode (DYN = false), every task, mapping and chart: the single-step kernels never touch scratch,
     # and neither do the T-step kernels of the lane-group mappings
     bad, n_noise = [], 0
