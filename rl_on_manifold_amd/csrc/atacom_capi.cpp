@@ -67,7 +67,8 @@ constexpr int kStatBlocks = 256;
 // and wins wherever it leaves half of the chip idle like the quad does at twice the batch (<= 4096 envs: 25.3 vs 26.0 us
 // per step, rollout kernels 22.0 vs 24.0 us per step, on every box tried).  At 8192 envs its 1024 waves occupy every CU:
 // the clock drops and the launch / load / store phase of a step grows, so single-step launches tie with the quad (27.2 us
-// both, mean of nine boxes; per box from 5 % faster to 4.5 % slower) and stay on the quad, while the T-step kernels --
+// both, mean of nine boxes; per box from 5 % faster to 4.5 % slower) and stayed on the quad through round 3 (round 4: 8
+// lanes, see pick_lanes_raw), while the T-step kernels --
 // state in registers, no per-step launch phase -- keep the 8-lane advantage (22.8 vs 23.9 us per step, with the policy
 // network 25.0 vs 26.5) and take it.  The state layout does not depend on the mapping, so the kernels of one handle may
 // differ.  planar (6 x 9): the quad is the widest that pays.
