@@ -39,9 +39,20 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in _sources())
 
 
+# kernel-tuning builds: ATACOM_KEEP_OBJ=1 keeps the objects of a build; ATACOM_ONLY_UNITS=a.hip,b.hip then recompiles only
+# those units (with ATACOM_HIPCC_FLAGS applied to them alone) and links against the kept objects of the others
+ONLY = [u for u in os.environ.get('ATACOM_ONLY_UNITS', '').split(',') if u]
+
+
 def _compile(unit):
     src = os.path.join(CSRC, unit)
-    obj = os.path.join(CSRC, os.path.splitext(unit)[0] + os.environ.get('ATACOM_OBJ_TAG', '') + '.o')
+    tag = os.environ.get('ATACOM_OBJ_TAG', '')
+    obj = os.path.join(CSRC, os.path.splitext(unit)[0] + tag + '.o')
+    if ONLY and unit not in ONLY:
+        kept = os.path.join(CSRC, os.path.splitext(unit)[0] + os.environ.get('ATACOM_BASE_TAG', '_keep') + '.o')
+        if not os.path.exists(kept):
+            raise RuntimeError('ATACOM_ONLY_UNITS needs the kept object %s (build once with ATACOM_KEEP_OBJ=1 ATACOM_OBJ_TAG=_keep)' % kept)
+        return kept
     cmd = [HIPCC] + FLAGS + UNIT_FLAGS.get(unit, []) + (['-x', 'hip'] if unit.endswith('.cpp') else []) + ['-c', src, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -60,8 +71,10 @@ def build(force=False, verbose=True):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n%s\n%s' % (' '.join(cmd), r.stderr[-4000:]))
-    for o in objs:
-        os.remove(o)
+    if not os.environ.get('ATACOM_KEEP_OBJ'):
+        for o in objs:
+            if not (ONLY and o.endswith(os.environ.get('ATACOM_BASE_TAG', '_keep') + '.o')):
+                os.remove(o)
     return LIB
 
 

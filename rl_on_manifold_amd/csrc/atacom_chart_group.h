@@ -233,17 +233,28 @@ __device__ __forceinline__ void canonical_mu_group3(const T (&A)[E::NC][E::NQ], 
         VL[sl][NQ] = cp.e6[sl] * hp;
         Ul[sl] = T(0);
     }
-    // x = -Gamma b:  z = L^-1 b = sum_i b_i v_i (group sum), x_i = -v_i . z
+    // x = -Gamma b:  z = L^-1 b by FORWARD SUBSTITUTION on the replicated factor with b gathered, x_i = -v_i . z.
+    // (First written as the group sum z = sum_i b_i v_i -- one product per lane, rounded on its own, then a tree of adds.  With a
+    // soft row of weight 1 / s^2 ~ 10^3 the entries of b are ~10^4 and cancel in z_k = (b_k - L_k0 z_0 - ...) / L_kk down to
+    // O(10): every separately rounded product left 6e-8 x 10^4 in z, x_0 inherited it, and the slack velocity
+    // w_g = -(y_g + A_g x) / s_g amplified it by 1 / s_g.  The planar float32 soak caught it: 64 samples of 295 k beyond the
+    // quick sensitivity bound against 1 for the second form -- whose z = Li b is one fused chain per entry, a single large
+    // rounding -- and 7 unexplained; found by giving the third form the second form's prologue piece by piece
+    // (profiles/r04_chart_form3_planar.md).  In the substitution every product is fused into the running remainder: the only
+    // roundings are of the small results.  Same instruction count: NQ broadcasts + NQ (NQ + 1) / 2 operations.)
     {
-        T z[NQ];
+        T bb[NQ], z[NQ];
+        static_for<0, NQ>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            bb[i] = qbcast<i % LG, LG>(bo[i / LG]);
+        });
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
-            T a = bo[0] * VL[0][k];
+            T a = bb[k];
 #pragma unroll
-            for (int sl = 1; sl < S6; ++sl) a = num<T>::fma(bo[sl], VL[sl][k], a);
-            z[k] = a;
+            for (int j = 0; j < k; ++j) a = num<T>::fma(-L[k][j], z[j], a);
+            z[k] = a * inv[k];
         }
-        gsum_all<LG>(z);
 #pragma unroll
         for (int sl = 0; sl < S; ++sl) {
             T a = T(0);

@@ -20,9 +20,6 @@
 namespace atacom {
 
 constexpr int WAVE = 64;
-#ifndef ATACOM_CHART_FORM3_PLANAR
-#define ATACOM_CHART_FORM3_PLANAR 0
-#endif
 // rigid-body kernels: park the held solver state in LDS across the dynamics (env_step); -DATACOM_DYN_PARK=0: the A/B build
 #ifndef ATACOM_DYN_PARK
 #define ATACOM_DYN_PARK 1
@@ -463,13 +460,7 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                                // slot (c-1) / LANES; column 0 is replicated and read from A directly, atacom_quad.h)
     T tlo[NQ], tup[NQ];         // acc_truncation bounds (atacom.py:117-121): functions of the controller's dq only
     // CANON, LANES > 1 (third form, atacom_chart_group.h): the lane's own columns / rows of A, built with A
-    // (iiwa only: on the planar task the third form is faster -- 10.8 against 13.6 us per step at 8192 environments -- but its
-    // float32 soak lost accuracy where a soft row's weight 1 / s^2 crosses 1 / tol^2 and a joint's pivot sits at the chart's
-    // threshold: 64 samples of 295 k beyond the quick sensitivity bound against 1 for the second form, 7 unexplained by the
-    // deep probe; the float64 instantiation is exact and the iiwa soaks of the two forms agree (9 against 8 samples).  Cause
-    // not found -- the two forms are the same arithmetic on paper, and the metric's rounding was ruled out by an A/B build
-    // (profiles/r04_chart_form3_planar.md) -- so the planar task keeps the second form.)
-    constexpr bool CANON3 = CANON && LANES > 1 && (ATACOM_CHART_FORM == 3) && (E::ID == 2 || ATACOM_CHART_FORM3_PLANAR);
+    constexpr bool CANON3 = CANON && LANES > 1 && (ATACOM_CHART_FORM == 3);
     [[maybe_unused]] ChartPre<T, E, LGC> cpre;
     auto prepare = [&](int sub) {
 #pragma unroll
