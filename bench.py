@@ -454,7 +454,8 @@ def main():
     result = None
     if rank == 0:
         traffic = None
-        traffic = measured_traffic(args.env, args.chart_mode) if B == {'circle': 4096}.get(args.env, 8192) else None
+        traffic = (measured_traffic(args.env, args.chart_mode, lanes=env.lanes_per_env)
+                   if B == {'circle': 4096}.get(args.env, 8192) else None)
         roof, roof_hbm = roofline_objects(args.env, B, kern_ms, traffic, args.chart_mode)
         result = {
             'metric': 'env-steps/sec', 'value': world * B * K / elapsed, 'unit': 'env-steps/s', 'n_gpus': world,
@@ -493,9 +494,11 @@ def main():
     return result
 
 
-def measured_traffic(name, chart='reference', dyn=False):
-    """HBM bytes per launch of the step kernel at the BASELINE batch, from the committed counter passes."""
-    tpath = os.path.join(ROOT, 'profiles', 'traffic_%s%s.json' % (name, '_dyn' if dyn else ('_canonical' if chart == 'canonical' else '')))
+def measured_traffic(name, chart='reference', dyn=False, lanes=0):
+    """HBM bytes per launch of the step kernel at the BASELINE batch, from the committed counter passes (iiwa on the
+    reference chart: one file per mapping the library may have timed in at create, 8 lanes or the quad)."""
+    suffix = '_dyn' if dyn else ('_canonical' if chart == 'canonical' else ('_quad' if name == 'iiwa' and lanes == 4 else ''))
+    tpath = os.path.join(ROOT, 'profiles', 'traffic_%s%s.json' % (name, suffix))
     try:
         return json.load(open(tpath)).get('hbm_bytes_per_launch')
     except Exception:  # noqa: BLE001

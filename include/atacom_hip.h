@@ -64,8 +64,12 @@ typedef struct atacom_config {
     int32_t lanes_per_env; /* kernel mapping: 1 = one env per lane, 2 = one env per lane pair, 4 = one env per DPP
                               quad, 8 = one env per 8 lanes (null-space solve split by column over the 2 / 4 / 8
                               lanes), 0 = let the library choose per env / batch / kernel (iiwa: 8 up to 8192
-                              envs, 4 up to 16384, 2 up to 32768, 1 beyond).
-                              Results are the same algorithm either way (summation order differs). */
+                              envs, 4 up to 16384, 2 up to 32768, 1 beyond; for atacom_step of iiwa on the
+                              reference chart at 4096 < batch <= 8192, where 8 lanes against 4 is decided by the
+                              box, atacom_create times both once per process, device and batch (about 20 ms; every
+                              later handle takes the same answer; ATACOM_CALIBRATE=0 in the environment keeps 8).
+                              Results are the same algorithm either way (summation order differs): name the
+                              mapping when runs on different machines must agree bit for bit. */
     double dt;           /* time_step */
     double rref_tol;     /* 0.05, atacom.py:128 */
     double action_penalty; /* env_hitting.py:10,68 */

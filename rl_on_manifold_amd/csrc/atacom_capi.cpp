@@ -4,8 +4,12 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "atacom_ops.h"
@@ -99,7 +103,9 @@ int pick_lanes_raw(const atacom_config& c, int kind) {
         // Round 4: single steps take the 8-lane mapping up to 8192 environments as well.  Rounds 2 / 3 had measured a tie with
         // the quad there (27.2 us both, mean of nine boxes, per box from -5 % to +4.5 %) and kept the quad; on the round-4
         // boxes the 8-lane kernel is 7 % faster every time -- bench workload 24.9 against 26.8 us (three interleaved runs),
-        // constraint-active states 25.9 against 27.8 (two more boxes): profiles/r04_ab_lanes_bench.log, r04_ab_noise_kernels.log
+        // constraint-active states 25.9 against 27.8 (two more boxes): profiles/r04_ab_lanes_bench.log, r04_ab_noise_kernels.log.
+        // A fifth box had it the other way round (27.6 against 26.9): for 4096 < batch <= 8192 this is only the static
+        // fallback, atacom_create times both mappings (calibrate_step_lanes below)
         (void)kind;
         return c.batch <= 8192 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));
     }
@@ -146,6 +152,7 @@ struct atacom_handle {
     double* partial_host;
     void* snap_dev;       // the header every snapshot image starts with (SnapHeader), device copy
     void* snap_host;      // pinned: atacom_snapshot_restore reads an image's header into it
+    int step_lanes;       // single-step mapping timed at create (calibrate_step_lanes), 0 = the static policy
 };
 
 // What a snapshot image starts with: enough of the configuration to refuse an image of another handle shape instead of
@@ -180,6 +187,85 @@ static Stepper stepper(const atacom_handle* h) {
     else if (c.chart_mode == 1) v = atacom::ops_chart(c.env_id, c.dtype);
     if (v) return {v->step, v->rollout, v->rollout_mlp};
     return {h->ops->step, h->ops->rollout, h->ops->rollout_mlp};
+}
+
+static int step_lanes(const atacom_handle* h) {
+    return h->step_lanes ? h->step_lanes : pick_lanes(h->cfg, KIND_STEP);
+}
+
+// Single steps of iiwa at 4096 < batch <= 8192 on the reference chart: 8 lanes per environment (1024 waves, every CU
+// busy) against the quad (512 waves, half of the CUs) is decided by the box, not by the kernel -- the 8-lane kernel has
+// 12 % fewer instructions per wave but runs at whatever clock a fully occupied chip is given: 24.9 against 26.8 us on
+// four of the five round-4 boxes, 27.6 against 26.9 on the fifth (profiles/r04_ab_lanes_bench*.log, r04_ab_block_group.log;
+// rounds 2 / 3: a tie over nine boxes, per box from -5 % to +4.5 %).  So lanes_per_env = 0 times both mappings once per
+// process, device and batch when the first such handle is created (three alternating bursts of 100 launches each,
+// the minimum per mapping: about 20 ms), and every later handle of the process
+// takes the same answer -- two handles of one process never differ in their summation order.  8 lanes unless the quad is
+// more than 1 % faster; ATACOM_CALIBRATE=0 in the environment keeps the static choice (8).  The T-step kernels do not
+// take part: no launch phase per step, 8 lanes win on every box.
+static bool wants_calibration(const atacom_config& c) {
+    if (c.lanes_per_env != 0 || c.env_id != ATACOM_ENV_IIWA || c.dtype != ATACOM_F32 || c.chart_mode != 0 ||
+        c.dynamics_mode != 0 || c.batch <= 4096 || c.batch > 8192)
+        return false;
+    const char* e = std::getenv("ATACOM_CALIBRATE");
+    return !(e && e[0] == '0');
+}
+static std::mutex g_cal_mutex;
+static std::map<std::pair<int, int>, int> g_cal_cache;          // (device, batch) -> lanes
+
+// Times atacom_step's kernel in both mappings on the handle's own (freshly reset) state; the caller re-initialises the
+// state afterwards.  Returns hipSuccess and the choice in h->step_lanes (left 0 if anything fails: the static policy).
+static hipError_t calibrate_step_lanes(atacom_handle* h) {
+    std::lock_guard<std::mutex> lock(g_cal_mutex);
+    const std::pair<int, int> key(h->device, h->cfg.batch);
+    auto it = g_cal_cache.find(key);
+    if (it != g_cal_cache.end()) { h->step_lanes = it->second; return hipSuccess; }
+    const size_t B = (size_t)h->cfg.batch, el = h->ops->elem;
+    void *act = nullptr, *obs = nullptr, *rew = nullptr;
+    uint8_t *absb = nullptr, *last = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(&act, el * B * h->ops->nk);
+    if (e == hipSuccess) e = hipMemset(act, 0, el * B * h->ops->nk);
+    if (e == hipSuccess) e = hipMalloc(&obs, el * B * h->ops->obs_dim);
+    if (e == hipSuccess) e = hipMalloc(&rew, el * B);
+    if (e == hipSuccess) e = hipMalloc((void**)&absb, B);
+    if (e == hipSuccess) e = hipMalloc((void**)&last, B);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    const int cand[2] = {8, 4};
+    float best[2] = {1e30f, 1e30f};
+    const Stepper st = stepper(h);
+    for (int round = 0; round < 3 && e == hipSuccess; ++round) {
+        for (int c = 0; c < 2 && e == hipSuccess; ++c) {
+            for (int i = 0; i < 8; ++i)
+                st.step(h->cfg, cand[c], h->f, h->ip, act, obs, rew, absb, last, nullptr, nullptr);
+            e = hipEventRecord(e0, nullptr);
+            for (int i = 0; i < 100; ++i)
+                st.step(h->cfg, cand[c], h->f, h->ip, act, obs, rew, absb, last, nullptr, nullptr);
+            if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e == hipSuccess && ms < best[c]) best[c] = ms;
+        }
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) {
+        h->step_lanes = best[1] < 0.99f * best[0] ? 4 : 8;
+        g_cal_cache[key] = h->step_lanes;
+        const char* v = std::getenv("ATACOM_CALIBRATE");
+        if (v && v[0] == 'v')                                   // ATACOM_CALIBRATE=verbose: say what was measured
+            std::fprintf(stderr, "[atacom] device %d, iiwa batch %d, atacom_step: 8 lanes %.2f us, 4 lanes %.2f us per launch -> %d\n",
+                         h->device, h->cfg.batch, best[0] * 10.f, best[1] * 10.f, h->step_lanes);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (act) (void)hipFree(act);
+    if (obs) (void)hipFree(obs);
+    if (rew) (void)hipFree(rew);
+    if (absb) (void)hipFree(absb);
+    if (last) (void)hipFree(last);
+    return e;
 }
 
 static int check_mlp(const atacom_handle* h, const atacom_mlp* net, const char* who) {
@@ -310,6 +396,7 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
     h->ops = ops;
     h->f = nullptr; h->ip = nullptr; h->partial_dev = nullptr; h->partial_host = nullptr;
     h->snap_dev = nullptr; h->snap_host = nullptr;
+    h->step_lanes = 0;
     const size_t B = (size_t)cfg->batch;
     void* drow = nullptr;
     // default initial state for every env, then a full reset
@@ -334,17 +421,24 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
     }
     if (e == hipSuccess) {
         what = "initialisation";
-        e = hipMemset(h->f, 0, ops->elem * ops->n_planes * B);
+        e = hipMemcpy(drow, bytes.data(), bytes.size(), hipMemcpyHostToDevice);
     }
-    if (e == hipSuccess) e = hipMemset(h->ip, 0, sizeof(int) * ops->n_iplanes * B);
-    if (e == hipSuccess) e = hipMemcpy(drow, bytes.data(), bytes.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
+    auto initialise = [&]() -> hipError_t {
+        hipError_t r = hipMemset(h->f, 0, ops->elem * ops->n_planes * B);
+        if (r == hipSuccess) r = hipMemset(h->ip, 0, sizeof(int) * ops->n_iplanes * B);
+        if (r != hipSuccess) return r;
         ops->fill_init(h->cfg, h->f, h->ip, drow, nullptr);
         ops->clear_stats(h->cfg, h->f, h->ip, nullptr);
         ops->reset(h->cfg, h->f, h->ip, nullptr, nullptr, nullptr, nullptr);
-        e = hipGetLastError();
+        r = hipGetLastError();
+        return r == hipSuccess ? hipDeviceSynchronize() : r;
+    };
+    if (e == hipSuccess) e = initialise();
+    if (e == hipSuccess && wants_calibration(h->cfg)) {
+        what = "timing the two single-step mappings";
+        e = calibrate_step_lanes(h);
+        if (e == hipSuccess) e = initialise();          // the timed launches stepped the state: start over
     }
-    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (drow) (void)hipFree(drow);
     if (e != hipSuccess) {                      // one exit for every failure: nothing allocated above survives it
         atacom_destroy(h);
@@ -381,7 +475,7 @@ int atacom_step(atacom_handle* h, const void* d_action, void* d_obs, void* d_rew
     if (!d_action || !d_obs || !d_reward || !d_absorbing)
         return fail(ATACOM_E_INVALID, "atacom_step: d_action, d_obs, d_reward and d_absorbing are required");
     ON_DEVICE(h);
-    stepper(h).step(h->cfg, pick_lanes(h->cfg, KIND_STEP), h->f, h->ip, d_action, d_obs, d_reward, d_absorbing, d_last,
+    stepper(h).step(h->cfg, step_lanes(h), h->f, h->ip, d_action, d_obs, d_reward, d_absorbing, d_last,
                     nullptr, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
@@ -393,7 +487,7 @@ int atacom_step_masked(atacom_handle* h, const uint8_t* d_mask, const void* d_ac
     if (!d_action || !d_obs || !d_reward || !d_absorbing)
         return fail(ATACOM_E_INVALID, "atacom_step_masked: d_action, d_obs, d_reward and d_absorbing are required");
     ON_DEVICE(h);
-    stepper(h).step(h->cfg, pick_lanes(h->cfg, KIND_STEP), h->f, h->ip, d_action, d_obs, d_reward, d_absorbing, d_last,
+    stepper(h).step(h->cfg, step_lanes(h), h->f, h->ip, d_action, d_obs, d_reward, d_absorbing, d_last,
                     d_mask, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
@@ -459,7 +553,7 @@ int atacom_rollout_packed(atacom_handle* h, int32_t n_steps, const void* d_actio
 
 int atacom_get_lanes(const atacom_handle* h, int32_t* out_step_lanes, int32_t* out_rollout_lanes) {
     if (!h) return fail(ATACOM_E_INVALID, "atacom_get_lanes: null handle");
-    if (out_step_lanes) *out_step_lanes = pick_lanes(h->cfg, KIND_STEP);
+    if (out_step_lanes) *out_step_lanes = step_lanes(h);
     if (out_rollout_lanes) *out_rollout_lanes = pick_lanes(h->cfg, KIND_ROLLOUT);
     return ATACOM_OK;
 }

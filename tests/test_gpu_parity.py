@@ -10,6 +10,8 @@ Stated tolerances
                   its 1/s slack dynamics show up in sens, a kernel bug does not.
                   Kinematics primitives: fixed absolute bounds stated in the tests.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -844,12 +846,27 @@ def test_host_side_error_paths_and_multiple_handles():
     with pytest.raises(AtacomError):
         BatchedAtacomEnv('planar', 4, lanes_per_env=3)
     # the mapping the library picks for lanes_per_env = 0 (atacom_capi.cpp: pick_lanes), and an explicit request is kept
-    for name, B, lanes in (('iiwa', 4096, 8), ('iiwa', 8192, 8), ('iiwa', 16384, 4), ('iiwa', 32768, 2), ('iiwa', 65536, 1),
+    for name, B, lanes in (('iiwa', 4096, 8), ('iiwa', 16384, 4), ('iiwa', 32768, 2), ('iiwa', 65536, 1),
                            ('planar', 8192, 4), ('planar', 65536, 1), ('circle', 4096, 1)):
         assert BatchedAtacomEnv(name, B, device=DEV).lanes_per_env == lanes, (name, B)
     assert BatchedAtacomEnv('iiwa', 8192, device=DEV, lanes_per_env=8).lanes_per_env == 8
-    e = BatchedAtacomEnv('iiwa', 8192, device=DEV)            # 8 lanes up to 8192 environments, single steps and T-step kernels
-    assert (e.lanes_per_env, e.rollout_lanes_per_env) == (8, 8)
+    # iiwa single steps at 4096 < batch <= 8192: 8 lanes against the quad is a property of the box, atacom_create times both
+    # (calibrate_step_lanes) -- once per process, so two handles agree and step alike bit for bit; the T-step kernels: 8
+    e = BatchedAtacomEnv('iiwa', 8192, device=DEV)
+    assert e.lanes_per_env in (4, 8) and e.rollout_lanes_per_env == 8
+    e_again = BatchedAtacomEnv('iiwa', 8192, device=DEV)
+    assert e_again.lanes_per_env == e.lanes_per_env
+    a8 = torch.full((8192, e.dims['null']), 0.25, device=DEV)
+    o_first = e.step(a8)[0]
+    assert torch.equal(o_first, e_again.step(a8)[0])
+    named = BatchedAtacomEnv('iiwa', 8192, device=DEV, lanes_per_env=e.lanes_per_env)      # no timing at create
+    assert torch.equal(named.step(a8)[0], o_first)              # the timed launches left no trace in the state
+    assert named.get_constraints_logs() == e.get_constraints_logs()
+    os.environ['ATACOM_CALIBRATE'] = '0'
+    try:
+        assert BatchedAtacomEnv('iiwa', 8192, device=DEV).lanes_per_env == 8           # the static policy
+    finally:
+        del os.environ['ATACOM_CALIBRATE']
     e = BatchedAtacomEnv('iiwa', 16384, device=DEV)
     assert (e.lanes_per_env, e.rollout_lanes_per_env) == (4, 4)
     assert BatchedAtacomEnv('iiwa', 64, device=DEV, dtype=torch.float64).lanes_per_env == 1
