@@ -104,8 +104,7 @@ int pick_lanes_raw(const atacom_config& c, int kind) {
         // the quad there (27.2 us both, mean of nine boxes, per box from -5 % to +4.5 %) and kept the quad; on the round-4
         // boxes the 8-lane kernel is 7 % faster every time -- bench workload 24.9 against 26.8 us (three interleaved runs),
         // constraint-active states 25.9 against 27.8 (two more boxes): profiles/r04_ab_lanes_bench.log, r04_ab_noise_kernels.log.
-        // A fifth box had it the other way round (27.6 against 26.9): for 4096 < batch <= 8192 this is only the static
-        // fallback, atacom_create times both mappings (calibrate_step_lanes below)
+        // For 4096 < batch <= 8192 this is the static fallback: atacom_create times both mappings (calibrate_step_lanes below)
         (void)kind;
         return c.batch <= 8192 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));
     }
@@ -194,15 +193,16 @@ static int step_lanes(const atacom_handle* h) {
 }
 
 // Single steps of iiwa at 4096 < batch <= 8192 on the reference chart: 8 lanes per environment (1024 waves, every CU
-// busy) against the quad (512 waves, half of the CUs) is decided by the box, not by the kernel -- the 8-lane kernel has
-// 12 % fewer instructions per wave but runs at whatever clock a fully occupied chip is given: 24.9 against 26.8 us on
-// four of the five round-4 boxes, 27.6 against 26.9 on the fifth (profiles/r04_ab_lanes_bench*.log, r04_ab_block_group.log;
-// rounds 2 / 3: a tie over nine boxes, per box from -5 % to +4.5 %).  So lanes_per_env = 0 times both mappings once per
-// process, device and batch when the first such handle is created (three alternating bursts of 100 launches each,
-// the minimum per mapping: about 20 ms), and every later handle of the process
-// takes the same answer -- two handles of one process never differ in their summation order.  8 lanes unless the quad is
-// more than 1 % faster; ATACOM_CALIBRATE=0 in the environment keeps the static choice (8).  The T-step kernels do not
-// take part: no launch phase per step, 8 lanes win on every box.
+// busy) against the quad (512 waves, half of the CUs).  The 8-lane kernel has 12 % fewer instructions per wave but runs at
+// whatever clock a fully occupied chip is given.  Rounds 2 / 3 measured a tie over nine boxes (per box from -5 % to +4.5 %)
+// and kept the quad; with round 4's kernels the sustained bench workload has 8 lanes ahead on every box it ran on (24.85
+// against 26.75 us, seven boxes: profiles/r04_calibration_probe.log, r04_calibration_vs_sustained.log, r04_ab_lanes_bench*.log).
+// A spread between boxes that once decided the sign is a reason not to hard-wire it: lanes_per_env = 0 times both mappings
+// once per process, device and batch when the first such handle is created (three alternating bursts of 100 launches
+// each, the minimum per mapping: about 20 ms), and every later handle of the process takes the same answer -- two handles
+// of one process never differ in their summation order.  8 lanes unless the quad is more than 1 % faster;
+// ATACOM_CALIBRATE=0 in the environment keeps the static choice (8), =verbose prints the two figures.  The T-step kernels
+// do not take part: no launch phase per step, 8 lanes win on every box.
 static bool wants_calibration(const atacom_config& c) {
     if (c.lanes_per_env != 0 || c.env_id != ATACOM_ENV_IIWA || c.dtype != ATACOM_F32 || c.chart_mode != 0 ||
         c.dynamics_mode != 0 || c.batch <= 4096 || c.batch > 8192)

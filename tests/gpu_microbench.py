@@ -22,6 +22,12 @@ for name in sys.argv[1:] or ['iiwa']:
         a = torch.rand((16, B, k), device=dev, generator=gen) * 2 - 1
         for i in range(int(os.environ.get('MB_WARM', '10'))): env.step_into(a[i % 16], env._obs, env._reward, env._absorbing, env._last)
         torch.cuda.synchronize()
+        # let the clocks settle: 100 launches are 3 ms, and the configuration measured first in a process read 1 - 1.5 us
+        # per step slower than the same configuration measured second (profiles/r04_microbench_order.log)
+        t_end = time.perf_counter() + float(os.environ.get('MB_SETTLE_MS', '300')) * 1e-3
+        while time.perf_counter() < t_end:
+            for i in range(64): env.step_into(a[i % 16], env._obs, env._reward, env._absorbing, env._last)
+            torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         n = 100
         e0.record()
