@@ -478,6 +478,41 @@ def test_step_into_rejects_what_the_raw_pointers_would_misread():
             env.step_into(**dict(good, **{key: bad}))
 
 
+def test_bound_step_is_step_into_with_the_checks_done_once():
+    """BatchedAtacomEnv.bind_step: same launches as step_into (plain and masked), the same refusals -- at bind time --,
+    the tensors kept alive by the callable, an error after close()."""
+    B, k, D = 64, 3, 12
+    e1, e2 = _env('planar', B), _env('planar', B)
+    gen = torch.Generator(device=DEV); gen.manual_seed(3)
+    acts = torch.rand((6, B, k), device=DEV, generator=gen) * 2 - 1
+    mask = (torch.arange(B, device=DEV) % 3 != 0).to(torch.uint8)
+
+    def bufs():
+        return (torch.empty((B, D), device=DEV), torch.empty((B,), device=DEV),
+                torch.empty((B,), device=DEV, dtype=torch.uint8), torch.empty((B,), device=DEV, dtype=torch.uint8))
+    o1, r1, a1, l1 = bufs()
+    o2, r2, a2, l2 = bufs()
+    plain = [e2.bind_step(acts[i], o2, r2, a2, l2) for i in range(6)]
+    masked = [e2.bind_step(acts[i], o2, r2, a2, l2, mask=mask) for i in range(6)]
+    for i in range(6):
+        m = mask if i % 2 else None
+        e1.step_into(acts[i], o1, r1, a1, l1, mask=m)
+        (masked if i % 2 else plain)[i]()
+        for x, y in ((o1, o2), (r1, r2), (a1, a2), (l1, l2)):
+            assert torch.equal(x, y)
+    assert torch.equal(e1.get_state(), e2.get_state())
+    with pytest.raises(ValueError):
+        e2.bind_step(acts[0].double(), o2, r2, a2, l2)
+    with pytest.raises(ValueError):
+        e2.bind_step(acts[0], o2, r2, a2.bool(), l2)
+    call = e2.bind_step(acts[0].clone(), *bufs())               # temporaries: the callable holds them
+    call()
+    torch.cuda.synchronize()
+    e2.close()
+    with pytest.raises(RuntimeError):
+        call()
+
+
 @pytest.mark.parametrize('name,kw', [('circle', {}), ('planar', {'task': 'D'}), ('iiwa', {'dynamics_mode': 'rigid_body'})])
 def test_snapshot_restore_reproduces_the_run_bit_for_bit(name, kw):
     """atacom_snapshot_save / _restore: the whole persistent state -- what get_state() returns AND the stored initial states,
