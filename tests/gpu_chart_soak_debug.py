@@ -23,7 +23,7 @@ envs = {dt: BatchedAtacomEnv(name, B, device='cuda:0', dtype=dt, lanes_per_env=l
         for dt in (torch.float32, torch.float64)}
 nq, ng = spec.dim_q, spec.n_g
 st0 = envs[torch.float32].get_state().cpu().numpy().astype(np.float64)
-rng = np.random.default_rng(11)
+rng = np.random.default_rng(int(os.environ.get('MB_SEED', '11')))
 o = ob.BatchedAtacomEnv(spec, B, init_q=st0[:, :nq] + rng.normal(0, 0.05, (B, nq)))
 rec = SensitivityRecorder(_step_outputs, seed=5)
 tag = os.path.basename(os.environ.get('ATACOM_LIB', 'default'))

@@ -25,7 +25,7 @@ for name, spec in (('circle', osc.circle_spec()), ('planar', osc.planar_spec()),
     env = BatchedAtacomEnv(name, B, device='cuda:0', dtype=DTYPE, lanes_per_env=lanes, chart_mode=CHART)
     nq, ng = spec.dim_q, spec.n_g
     st0 = env.get_state().cpu().numpy().astype(np.float64)
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(int(os.environ.get('MB_SEED', '11')))      # 11: the seed of every committed soak but the *_seed23 ones
     o = ob.BatchedAtacomEnv(spec, B, init_q=st0[:, :nq] + (rng.normal(0, 0.05, (B, nq)) if name != 'circle' else 0.0))
     o.track_margins()
     rec = SensitivityRecorder(_step_outputs, seed=5)
