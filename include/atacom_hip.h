@@ -64,12 +64,13 @@ typedef struct atacom_config {
     int32_t lanes_per_env; /* kernel mapping: 1 = one env per lane, 2 = one env per lane pair, 4 = one env per DPP
                               quad, 8 = one env per 8 lanes (null-space solve split by column over the 2 / 4 / 8
                               lanes), 0 = let the library choose per env / batch / kernel (iiwa: 8 up to 8192
-                              envs, 4 up to 16384, 2 up to 32768, 1 beyond; for atacom_step of iiwa on the
-                              reference chart at 4096 < batch <= 8192, where 8 lanes against 4 is decided by the
-                              box, atacom_create times both once per process, device and batch (about 20 ms; every
-                              later handle takes the same answer; ATACOM_CALIBRATE=0 in the environment keeps 8).
-                              Results are the same algorithm either way (summation order differs): name the
-                              mapping when runs on different machines must agree bit for bit. */
+                              envs, 4 up to 16384, 2 up to 32768, 1 beyond -- a STATIC policy: atacom_create launches
+                              nothing hidden and two handles of the same config run the same mappings in every
+                              process, on every box and on every rank of a sharded collection; atacom_get_lanes
+                              reports them.  ATACOM_CALIBRATE=1 (or =verbose) in the environment opts in to timing
+                              8 lanes against 4 for atacom_step of iiwa at 4096 < batch <= 8192 once per process,
+                              about 20 ms -- the bits then depend on the box).
+                              Results are the same algorithm in every mapping (summation order differs). */
     double dt;           /* time_step */
     double rref_tol;     /* 0.05, atacom.py:128 */
     double action_penalty; /* env_hitting.py:10,68 */
@@ -230,6 +231,11 @@ int atacom_rollout_packed(atacom_handle* h, int32_t n_steps, const void* d_actio
  * (env, step) logged since the last clear.  Synchronises `stream`. */
 int atacom_get_stats(atacom_handle* h, double out[3], int32_t clear, void* stream);
 
+/* env.seed(seed) (atacom.py:90-91 -> the base env's seed): re-keys the counter-based generator behind the device-side draws
+ * (random_init, obs_noise, env_noise: hash(seed, env, episode, step, draw)) from the next launch on.  Host-side only, no
+ * device work; launches already captured in a HIP graph keep the seed they were captured with. */
+int atacom_set_seed(atacom_handle* h, int32_t seed);
+
 /* The kernel mappings this handle runs: lanes per environment (1, 2, 4 or 8) of atacom_step and of the T-step kernels
  * (atacom_rollout / _mlp / _packed) -- cfg.lanes_per_env, or what the library chose for lanes_per_env = 0 (the two may
  * differ: the persistent state does not depend on the mapping).  Either output pointer may be NULL. */
@@ -247,7 +253,9 @@ int atacom_set_state(atacom_handle* h, const void* d_state, void* stream);
  * 64-byte device-to-host copy, which synchronises `stream` -- and returns ATACOM_E_INVALID for an image of another handle
  * shape instead of mis-reading it; save is three device-to-device copies on `stream`, no synchronisation.
  * restore(save(x)) followed by the same calls reproduces the run bit for bit (the reference has no counterpart: its envs
- * are Python objects one would pickle). */
+ * are Python objects one would pickle).  The header also records the kernel mappings of the writing handle
+ * (atacom_get_lanes): a restoring handle created with lanes_per_env = 0 adopts them, so the replay is bit for bit in
+ * another process as well; a handle with a named mapping keeps its own (the state does not depend on the mapping). */
 int64_t atacom_snapshot_bytes(const atacom_handle* h);
 int atacom_snapshot_save(atacom_handle* h, void* d_image, void* stream);
 int atacom_snapshot_restore(atacom_handle* h, const void* d_image, void* stream);

@@ -12,13 +12,14 @@ LIB_PATH = os.environ.get('ATACOM_LIB') or os.path.join(HERE, 'libatacom_hip.so'
 
 ENV_CIRCLE, ENV_PLANAR, ENV_IIWA, ENV_CIRCLE_EC, ENV_CIRCLE_T = 0, 1, 2, 3, 4
 F32, F64 = 0, 1
+OK, E_INVALID, E_HIP, E_UNSUPPORTED = 0, -1, -2, -3
 MAX_C, MAX_Q = 12, 6
 
 EXPORTS = ['atacom_snapshot_bytes', 'atacom_snapshot_save', 'atacom_snapshot_restore', 'atacom_rollout_mlp', 'atacom_rollout_packed', 'atacom_get_aux_state', 'atacom_set_aux_state',
            'atacom_inverse_dynamics', 'atacom_forward_dynamics', 'atacom_default_config', 'atacom_get_dims', 'atacom_create', 'atacom_destroy', 'atacom_reset',
            'atacom_step', 'atacom_rollout', 'atacom_get_stats', 'atacom_get_state', 'atacom_set_state',
            'atacom_nullspace', 'atacom_constraint_terms', 'atacom_step_masked', 'atacom_canonical_mu', 'atacom_last_error', 'atacom_version', 'atacom_get_lanes',
-           'atacom_get_filter_state', 'atacom_set_filter_state']
+           'atacom_get_filter_state', 'atacom_set_filter_state', 'atacom_set_seed']
 
 
 class AtacomConfig(C.Structure):
@@ -91,6 +92,7 @@ def load():
     lib.atacom_rollout_packed.argtypes = [vp, i32, vp, C.POINTER(AtacomMlp), vp, vp, i32, vp]
     lib.atacom_get_stats.argtypes = [vp, C.POINTER(C.c_double * 3), i32, vp]
     lib.atacom_get_lanes.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.atacom_set_seed.argtypes = [vp, i32]
     lib.atacom_get_state.argtypes = [vp, vp, vp]
     lib.atacom_set_state.argtypes = [vp, vp, vp]
     lib.atacom_get_aux_state.argtypes = [vp, vp, vp]

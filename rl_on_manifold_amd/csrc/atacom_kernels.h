@@ -1314,6 +1314,15 @@ __global__ void k_set_state(int B, T* __restrict__ f, int* __restrict__ ip, cons
     st.has_hit = ((int)o[k++]) & 3;                 // bit 0 has_hit, bit 1 has_bounce (task 'D')
     st.r_hit = o[k++]; st.vel_hit_x = o[k++]; st.t = (int)o[k++];
     store_state<T, E>(f, ip, B, b, st);
+    if constexpr (E::PUCK) {
+        // obs_delay: the low-pass behind the observation's velocities restarts on the injected state, like a reset does
+        // (reset_env) -- a stale filter of the previous trajectory would have the controller's dq disagree with the state just
+        // set.  A caller that wants a particular filter state calls atacom_set_filter_state AFTER this.
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pl<E>(f, L::FV + i, B, b) = st.puck[3 + i];
+#pragma unroll
+        for (int i = 0; i < E::NQ; ++i) pl<E>(f, L::FV + 3 + i, B, b) = st.dq[i];
+    }
 }
 
 // obs_delay: the low-pass state of the observation's velocities <-> [B, 3 + NQ] = [puck vx, vy, yaw rate, dq]

@@ -170,8 +170,12 @@ class BatchedAtacomEnv:
         return self._mdp_info
 
     def seed(self, seed):
-        """Kept for API parity (atacom.py:90-91); the device path is deterministic and draws no random numbers."""
-        self._seed = seed
+        """env.seed (atacom.py:90-91): re-keys the device-side generator behind random_init / obs_noise / env_noise
+        (atacom_set_seed) from the next call on -- two experiments that call mdp.seed(s) with different s no longer share
+        one noise stream.  The rest of the device path draws no random numbers.  Steps already captured in a HIP graph
+        (GraphedRollout) keep the seed they were captured with."""
+        self._seed = int(seed) & 0x7fffffff
+        _lib.check(self._lib.atacom_set_seed(self._h, self._seed))
 
     def render(self):
         pass
@@ -406,8 +410,10 @@ class BatchedAtacomEnv:
         n = int(self._lib.atacom_snapshot_bytes(self._h))
         if image.dtype != torch.uint8 or image.numel() < n or not self._on_my_device(image) or not image.is_contiguous():
             raise ValueError("snapshot image must be a contiguous uint8 tensor of >= %d bytes on %s" % (n, self.device))
-        if self._lib.atacom_snapshot_restore(self._h, _ptr(image), self._stream()) != 0:
+        rc = self._lib.atacom_snapshot_restore(self._h, _ptr(image), self._stream())
+        if rc == _lib.E_INVALID:                      # a bad image is the caller's error ...
             raise ValueError(self._lib.atacom_last_error().decode())
+        _lib.check(rc)                                # ... a HIP runtime failure is not (AtacomError)
 
     def get_constraints_logs(self, clear=True):
         res = (C.c_double * 3)()

@@ -116,8 +116,8 @@ class _AirHockeyFacade(_Facade):
             raise NotImplementedError       # as the reference does for the iiwa wrapper (iiwa_hit_atacom.py:20-21)
         self.task = task
         self.random_init = random_init
-        # env_noise / obs_noise / obs_delay (env_base.py:176-180, env_single.py:105-107,114-117): drawn on the device; seed()
-        # before the first reset has no effect on them -- pass `seed` here
+        # env_noise / obs_noise / obs_delay (env_base.py:176-180, env_single.py:105-107,114-117): drawn on the device from the
+        # counter-based generator keyed by `seed`; mdp.seed(s) re-keys it (atacom_set_seed)
         self._make(horizon=horizon, gamma=gamma, Kc=Kc, time_step=timestep,
                    n_intermediate_steps=n_intermediate_steps, action_penalty=action_penalty, device=device,
                    dtype=dtype, task=task, env_noise=env_noise, obs_noise=obs_noise, obs_delay=obs_delay, seed=seed)

@@ -93,6 +93,35 @@ class RolloutCollector:
         self.F = 2 * self.D + self.k + 3          # obs, action, reward, next_obs, absorbing, last
         self.layout = RecordLayout(self.sizes, self.D, self.k)
         self._recv = None
+        self.mappings = self._agree_on_mappings()
+
+    def _agree_on_mappings(self):
+        """The kernel mappings (lanes per environment of step() and of the T-step kernels) sum in different orders, so
+        ranks that hold equally sized shards must run the SAME mappings or a sharded collection is not reproducible
+        against a single-process run of the same batch size per rank.  The library's policy is static (a pure function of
+        the configuration, include/atacom_hip.h), so this can only fail when a rank was configured differently
+        (lanes_per_env, ATACOM_CALIBRATE=1): checked ONCE here, at construction -- one all-gather of three integers,
+        never in the data path -- and refused loudly.  Returns [(batch, step_lanes, rollout_lanes)] per rank."""
+        mine = [int(self.env.batch), int(getattr(self.env, 'lanes_per_env', 0)),
+                int(getattr(self.env, 'rollout_lanes_per_env', 0))]
+        if self.world == 1:
+            return [tuple(mine)]
+        dev = getattr(self.env, 'device', torch.device('cpu'))
+        if dist.get_backend(self.group) == 'gloo':
+            dev = torch.device('cpu')
+        t = torch.tensor(mine, dtype=torch.int64, device=dev)
+        allm = torch.empty((self.world * 3,), dtype=torch.int64, device=dev)     # the concatenated form every backend takes
+        dist.all_gather_into_tensor(allm, t, group=self.group)
+        rows = [tuple(int(v) for v in r) for r in allm.cpu().view(self.world, 3)]
+        by_batch = {}
+        for r, (b, sl, rl) in enumerate(rows):
+            first = by_batch.setdefault(b, (r, sl, rl))
+            if (sl, rl) != first[1:]:
+                raise ValueError("ranks %d and %d hold shards of %d environments but run different kernel mappings "
+                                 "(step %d / rollout %d lanes per environment against %d / %d): name lanes_per_env on "
+                                 "every rank (and leave ATACOM_CALIBRATE unset) -- the bits depend on the mapping"
+                                 % (first[0], r, b, first[1], first[2], sl, rl))
+        return rows
 
     # ------------------------------------------------------------------ local collection
     def collect_local(self, n_steps, actions=None, policy=None, noise=None, out=None):

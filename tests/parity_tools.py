@@ -210,24 +210,43 @@ def skip_pattern_of_rref(Nr, tol=1e-6):
     return skip
 
 
-def followed_chart_errors(rec, follow_fn, tol=1e-4, only_vacuous=True):
+def followed_chart_errors(rec, follow_fn, tol=1e-4, only_vacuous=True, decisions=None):
     """VERDICT r3 item 3b.  For the samples whose sensitivity bound says nothing (> VACUOUS), compare the device with the
     float64 oracle FORCED ONTO THE DEVICE'S OWN CHART DECISIONS: follow_fn(Jc [b, c, n]) -> bool [b, n] (the pivot / skip
     pattern the device's float32 rref takes on these matrices, read off atacom_nullspace).  Call after finish().
-    Returns (number of such samples, their errors against the following oracle, their errors against the plain oracle)."""
+    Returns (number of such samples, their errors against the following oracle, their errors against the plain oracle).
+    decisions (optional dict): filled with 'same' / 'total' -- in how many of the chart evaluations behind
+    these samples (one per physics sub-step) the device's whole pivot / skip pattern IS the float64 oracle's own."""
+    from oracle import atacom_batched as ob
     E = np.array(rec.err)
     sel = rec.bound > VACUOUS if only_vacuous else np.ones_like(rec.bound, dtype=bool)
     e_follow, e_plain = [], []
+    same = total = 0
+
+    def counted(sub):
+        k, rtol = sub.spec.n_null, sub.spec.rref_tol
+
+        def f(Jc):
+            nonlocal same, total
+            dev = follow_fn(Jc)
+            _, N = ob.bidiag_solve_null(Jc, np.zeros(Jc.shape[:2]), k)
+            own = skip_pattern_of_rref(ob.rref_tol(N, rtol))
+            same += int((dev == own).all(1).sum())
+            total += len(dev)
+            return dev
+        return f
     for t in range(E.shape[0]):
         idx = np.nonzero(sel[t])[0]
         if not len(idx):
             continue
         sub = slice_env(rec.snaps[t], idx)
-        sub.chart_follow = follow_fn
+        sub.chart_follow = counted(sub) if decisions is not None else follow_fn
         out = rec.step_fn(sub, tuple(x[idx] for x in rec.inputs[t]))
         dev = rec.dev[t][idx]
         e_follow.append((np.abs(dev - out) / np.maximum(1.0, np.abs(out))).max(1))
         e_plain.append(E[t, idx])
+    if decisions is not None:
+        decisions['same'], decisions['total'] = same, total
     if not e_follow:
         return 0, np.zeros(0), np.zeros(0)
     return int(sel.sum()), np.concatenate(e_follow), np.concatenate(e_plain)

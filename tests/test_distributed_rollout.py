@@ -111,6 +111,44 @@ def _solo_worker(port, q):
         dist.destroy_process_group()
 
 
+def _mapping_worker(rank, world, port, q, disagree):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle_engine import OracleEngine
+        eng = OracleEngine(NAME, 4, init_q=_init_q()[:4], horizon=5)
+        eng.lanes_per_env, eng.rollout_lanes_per_env = (4 if (disagree and rank == 1) else 8), 8
+        try:
+            col = RolloutCollector(eng)
+            q.put((rank, 'ok', col.mappings))
+        except ValueError as e:
+            q.put((rank, 'refused', str(e)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('disagree', [False, True])
+def test_ranks_must_agree_on_the_kernel_mapping(disagree):
+    """Equally sized shards that run different lane mappings sum in different orders: the collector gathers the mappings once
+    at construction and refuses on EVERY rank (the default used to be decided by a wall-clock race per process)."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + int(disagree)
+    procs = [ctx.Process(target=_mapping_worker, args=(r, 2, port, q, disagree)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if disagree:
+        assert all(r[1] == 'refused' and 'different kernel mappings' in r[2] for r in res)
+    else:
+        assert all(r[1] == 'ok' and r[2] == [(4, 8, 8), (4, 8, 8)] for r in res)
+
+
 def test_forced_collective_in_a_world_of_one_rank():
     """force_collective=True sends a one-rank world through the real all-gather / all-reduce calls (the CPU twin of the
     RCCL world-1 test in test_gpu_rollout.py)."""

@@ -179,24 +179,34 @@ def _device_chart_decisions(name, lanes):
     return follow
 
 
-def _followed_chart_report(rec, name, lanes, tol=1e-4, max_outside=0.07):
+MIN_SAME_DECISIONS = 0.99      # share of the chart evaluations behind the vacuous samples on which the float32 device takes
+                               # the float64 oracle's own pivot / skip pattern (asserted, not printed)
+
+
+def _followed_chart_report(rec, name, lanes, tol=1e-4, max_outside=0.07, p99_max=3e-4):
     """Where the sensitivity bound is vacuous (the reference's tolerance regime), the device is compared with the float64
     oracle FORCED ONTO THE DEVICE'S OWN CHART DECISIONS: discrete disagreement removed, what is left
     is arithmetic.  First measurement (1024 x 40 states around the reset pose, one environment per lane, 12960 samples with a
     vacuous bound): median 5e-6, p90 5e-5, p99 3e-4, 4.1 % above 1e-4 -- and EXACTLY the same numbers against the plain
     oracle: on these samples the float32 device and the float64 oracle already take the same pivot / skip decisions; what
     makes the bound vacuous is the continuous sensitivity of LAPACK's null basis inside the tolerance branch (zeroing
-    basis-dependent entries), not a discrete flip.  So the rule here is statistical, on top of the
-    per-sample bound: at most 7 % of these samples above 1e-4, 99 % within 1e-3, median at rounding level."""
+    basis-dependent entries), not a discrete flip.  Round 5 ASSERTS that claim instead of printing it: the
+    device's whole pivot / skip pattern equals the oracle's own on >= 99 % of the chart evaluations behind these samples
+    (one per physics sub-step), and the residual against the oracle forced onto the device's decisions is bounded on top of the
+    per-sample rule: at most 7 % of these samples above 1e-4, p99 below `p99_max`, median at rounding level."""
     from parity_tools import followed_chart_errors
-    n, e_f, e_p = followed_chart_errors(rec, _device_chart_decisions(name, lanes))
+    dec = {}
+    n, e_f, e_p = followed_chart_errors(rec, _device_chart_decisions(name, lanes), decisions=dec)
     if n == 0:
         return 'no vacuous samples'
-    msg = ('%s lanes %d, %d samples with a vacuous bound: against the oracle on the device\'s chart decisions median %.2e / p90 '
-           '%.2e / p99 %.2e / max %.2e, %.2f %% above %.0e (against the plain oracle: median %.2e, %.2f %% above)'
-           % (name, lanes, n, np.median(e_f), np.quantile(e_f, 0.9), np.quantile(e_f, 0.99), e_f.max(), 100 * np.mean(e_f > tol),
-              tol, np.median(e_p), 100 * np.mean(e_p > tol)))
-    assert np.mean(e_f > tol) <= max_outside and np.quantile(e_f, 0.99) < 1e-3 and np.median(e_f) < 2e-5, msg
+    same = dec['same'] / max(dec['total'], 1)
+    msg = ('%s lanes %d, %d samples with a vacuous bound: device pivot / skip pattern == the oracle\'s own on %.3f %% of %d chart '
+           'evaluations; against the oracle on the device\'s chart decisions median %.2e / p90 '
+           '%.2e / p99 %.2e / max %.2e, %.2f %% above %.0e (against the plain oracle: median %.2e, p99 %.2e, %.2f %% above)'
+           % (name, lanes, n, 100 * same, dec['total'], np.median(e_f), np.quantile(e_f, 0.9), np.quantile(e_f, 0.99), e_f.max(),
+              100 * np.mean(e_f > tol), tol, np.median(e_p), np.quantile(e_p, 0.99), 100 * np.mean(e_p > tol)))
+    assert same >= MIN_SAME_DECISIONS, msg
+    assert np.mean(e_f > tol) <= max_outside and np.quantile(e_f, 0.99) < p99_max and np.median(e_f) < 2e-5, msg
     return msg
 
 
@@ -226,7 +236,7 @@ def test_env_step_teacher_forced_against_oracle(name, dt, lanes):
     if dt == 'f64':
         assert np.max(rec.err) < 1e-8, np.max(rec.err)
     else:
-        print(rec.finish('%s lanes %d' % (name, lanes), max_vacuous={'circle': 0.0, 'planar': 0.005, 'iiwa': 0.35}[name]))
+        print(rec.finish('%s lanes %d' % (name, lanes), max_vacuous={'circle': 0.0, 'planar': 0.005, 'iiwa': 0.35}[name]))      # measured 31.64 % (iiwa), 0.19 % (planar)
         if name == 'iiwa':
             print(_followed_chart_report(rec, name, lanes))
     # constraint statistics accumulated on the device == oracle's (A13)
@@ -287,7 +297,7 @@ def test_iiwa_step_teacher_forced_away_from_the_planar_pose(chart, dt, lanes):
         assert np.max(rec.err) < 1e-8, np.max(rec.err)
         return
     print(rec.finish('iiwa away from the planar pose, %s chart, lanes %d' % (chart, lanes),
-                     max_vacuous={'reference': 0.30, 'canonical': 0.05}[chart]))
+                     max_vacuous={'reference': 0.27, 'canonical': 0.05}[chart]))         # measured 22.29 % / 2.56 %
     if chart == 'reference':
         print(_followed_chart_report(rec, 'iiwa', lanes))
 
@@ -850,21 +860,27 @@ def test_host_side_error_paths_and_multiple_handles():
                            ('planar', 8192, 4), ('planar', 65536, 1), ('circle', 4096, 1)):
         assert BatchedAtacomEnv(name, B, device=DEV).lanes_per_env == lanes, (name, B)
     assert BatchedAtacomEnv('iiwa', 8192, device=DEV, lanes_per_env=8).lanes_per_env == 8
-    # iiwa single steps at 4096 < batch <= 8192: 8 lanes against the quad is a property of the box, atacom_create times both
-    # (calibrate_step_lanes) -- once per process, so two handles agree and step alike bit for bit; the T-step kernels: 8
+    # iiwa single steps at 4096 < batch <= 8192: the STATIC policy is 8 lanes -- atacom_create launches nothing hidden and the
+    # mapping (hence the bits) is the same in every process, on every box, on every rank (the cross-
+    # process check is test_default_mapping_is_deterministic_across_processes in test_gpu_rollout.py)
+    assert os.environ.get('ATACOM_CALIBRATE') is None
     e = BatchedAtacomEnv('iiwa', 8192, device=DEV)
-    assert e.lanes_per_env in (4, 8) and e.rollout_lanes_per_env == 8
-    e_again = BatchedAtacomEnv('iiwa', 8192, device=DEV)
-    assert e_again.lanes_per_env == e.lanes_per_env
+    assert (e.lanes_per_env, e.rollout_lanes_per_env) == (8, 8)
     a8 = torch.full((8192, e.dims['null']), 0.25, device=DEV)
     o_first = e.step(a8)[0]
-    assert torch.equal(o_first, e_again.step(a8)[0])
-    named = BatchedAtacomEnv('iiwa', 8192, device=DEV, lanes_per_env=e.lanes_per_env)      # no timing at create
-    assert torch.equal(named.step(a8)[0], o_first)              # the timed launches left no trace in the state
+    named = BatchedAtacomEnv('iiwa', 8192, device=DEV, lanes_per_env=8)
+    assert torch.equal(named.step(a8)[0], o_first)
     assert named.get_constraints_logs() == e.get_constraints_logs()
-    os.environ['ATACOM_CALIBRATE'] = '0'
+    # the timing of 8 lanes against the quad is opt-in (ATACOM_CALIBRATE=1 / verbose): whatever it picks, the timed launches
+    # leave no trace in the state, and a second handle of the process takes the same answer
+    os.environ['ATACOM_CALIBRATE'] = '1'
     try:
-        assert BatchedAtacomEnv('iiwa', 8192, device=DEV).lanes_per_env == 8           # the static policy
+        c1 = BatchedAtacomEnv('iiwa', 8192, device=DEV)
+        c2 = BatchedAtacomEnv('iiwa', 8192, device=DEV)
+        assert c1.lanes_per_env in (4, 8) and c2.lanes_per_env == c1.lanes_per_env and c1.rollout_lanes_per_env == 8
+        twin = BatchedAtacomEnv('iiwa', 8192, device=DEV, lanes_per_env=c1.lanes_per_env)
+        assert torch.equal(c1.step(a8)[0], twin.step(a8)[0])
+        assert c1.get_constraints_logs() == twin.get_constraints_logs()
     finally:
         del os.environ['ATACOM_CALIBRATE']
     e = BatchedAtacomEnv('iiwa', 16384, device=DEV)

@@ -559,6 +559,72 @@ def test_snapshot_restore_reproduces_the_run_bit_for_bit(name, kw):
     assert torch.equal(env.snapshot(), image)
 
 
+_DETERMINISM_CHILD = r"""
+import hashlib, sys, torch
+sys.path.insert(0, %(root)r)
+from rl_on_manifold_amd import BatchedAtacomEnv
+env = BatchedAtacomEnv('iiwa', 8192, device='cuda:0', auto_reset=True)          # lanes_per_env = 0: the library's choice
+image = torch.load(%(image)r).to('cuda:0')
+acts = torch.load(%(acts)r).to('cuda:0')
+env.restore(image)
+h = hashlib.sha256()
+for t in range(acts.shape[0]):
+    o, r, ab, info = env.step(acts[t])
+    for x in (o, r, ab, info['last']):
+        h.update(x.cpu().numpy().tobytes())
+roll = env.rollout(acts[:8])
+for k in sorted(roll):
+    h.update(roll[k].cpu().numpy().tobytes())
+h.update(env.snapshot().cpu().numpy().tobytes())
+print('RESULT', env.lanes_per_env, env.rollout_lanes_per_env, h.hexdigest())
+"""
+
+
+def test_default_mapping_is_deterministic_across_processes(tmp_path):
+    """VERDICT r4 weak 2 / ADVICE r4: two FRESH processes create the default handle (lanes_per_env = 0) at the headline
+    batch, must report the same kernel mappings and -- restored from one snapshot -- produce 50 steps, a T-step rollout and
+    a final state that are bit-identical.  (Round 4 chose 8 lanes against 4 by timing both at create: a wall-clock race per
+    process.)  The same snapshot restored into a handle created with ANOTHER named mapping still replays the writer's bits
+    if that handle left the choice to the library, because the image carries the writer's mappings."""
+    from rl_on_manifold_amd import BatchedAtacomEnv
+    B, T = 8192, 50
+    env = BatchedAtacomEnv('iiwa', B, device=DEV, auto_reset=True, random_init=True, seed=11)
+    env.reset()
+    g = torch.Generator(device='cpu').manual_seed(5)
+    acts = torch.rand(T, B, env.dims['null'], generator=g) * 2.4 - 1.2
+    env.rollout(acts[:30].to(DEV))                                  # off the reset pose, some auto-resets
+    image = env.snapshot()
+    torch.save(image.cpu(), str(tmp_path / 'image.pt'))
+    torch.save(acts, str(tmp_path / 'acts.pt'))
+    code = _DETERMINISM_CHILD % {'root': ROOT, 'image': str(tmp_path / 'image.pt'), 'acts': str(tmp_path / 'acts.pt')}
+    envv = {k: v for k, v in os.environ.items() if k != 'ATACOM_CALIBRATE'}
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=envv)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith('RESULT')][-1].split())
+    assert outs[0] == outs[1], outs
+    assert outs[0][1:3] == ['8', '8']                                # the static policy at this batch
+    # a quad-mapped writer: an auto handle adopts the image's mappings and replays its bits; a named handle keeps its own
+    quad = BatchedAtacomEnv('iiwa', B, device=DEV, auto_reset=True, lanes_per_env=4)
+    quad.restore(image)
+    assert quad.lanes_per_env == 4                                  # named: kept
+    a0 = acts[0].to(DEV)
+    want = quad.step(a0)
+    qimg_env = BatchedAtacomEnv('iiwa', B, device=DEV, auto_reset=True, lanes_per_env=4)
+    qimg_env.restore(image)
+    qimg = qimg_env.snapshot()                                      # an image written by a quad handle
+    auto = BatchedAtacomEnv('iiwa', B, device=DEV, auto_reset=True)
+    assert auto.lanes_per_env == 8
+    auto.restore(qimg)
+    assert (auto.lanes_per_env, auto.rollout_lanes_per_env) == (4, 4)          # adopted
+    got = auto.step(a0)
+    for x, y in zip(want[:3], got[:3]):
+        assert torch.equal(x, y)
+    auto.restore(image)                                             # and back to the 8-lane writer's mappings
+    assert (auto.lanes_per_env, auto.rollout_lanes_per_env) == (8, 8)
+
+
 def test_graphed_rollout_leaves_no_warmup_residue():
     """GraphedRollout warms up with real steps before the capture: they must not stay in the constraint
     statistics nor shift the device-side random resets -- the first replay equals the rollout kernel of a twin engine that
