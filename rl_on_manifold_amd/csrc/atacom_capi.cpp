@@ -90,7 +90,13 @@ enum { KIND_STEP = 0, KIND_ROLLOUT = 1 };
 int pick_lanes_raw(const atacom_config& c, int kind) {
     if (c.lanes_per_env == 1 || c.lanes_per_env == 2 || c.lanes_per_env == 4 || c.lanes_per_env == 8)
         return c.lanes_per_env;
-    if (c.dtype == ATACOM_F64) return 1;
+    if (c.dtype == ATACOM_F64) {
+        // float64 (the parity build, and the bench's reference-precision record): one environment per lane, except iiwa up
+        // to 8192 environments, where the 8-lane kernels are 30 % faster (112.7 against 161.3 us per step, T-step 94.4
+        // against 155.8: profiles/r05_f64_lanes.log) -- the same "widest mapping whose waves find a SIMD each" rule
+        if (c.env_id == ATACOM_ENV_IIWA && c.chart_mode == 0 && c.batch <= 8192) return 8;
+        return 1;
+    }
     if (c.chart_mode == 1) {
         if (c.env_id == ATACOM_ENV_IIWA) {
             if (kind == KIND_STEP) return c.batch <= 8192 ? 8 : (c.batch <= 16384 ? 4 : 1);
@@ -109,8 +115,13 @@ int pick_lanes_raw(const atacom_config& c, int kind) {
         (void)kind;
         return c.batch <= 8192 ? 8 : (c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1));
     }
-    if (c.env_id == ATACOM_ENV_PLANAR)
+    if (c.env_id == ATACOM_ENV_PLANAR) {
+        // round 5 re-measured 8 lanes against the quad at 8192 environments with this round's kernels: single steps tie
+        // (10.9 us both: the quad stays, half the waves), the T-step kernels run 8.3 against 8.8 us per step on 8 lanes
+        // (profiles/r05_planar_lanes_baseline.log)
+        if (kind == KIND_ROLLOUT && c.batch <= 8192) return 8;
         return c.batch <= 16384 ? 4 : (c.batch <= 32768 ? 2 : 1);
+    }
     return 1;                                                              // circle: launch-bound either way
 }
 int pick_lanes(const atacom_config& c, int kind) {

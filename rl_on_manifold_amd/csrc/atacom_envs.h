@@ -175,8 +175,10 @@ struct IiwaKin {
     T p4[3], p7[3], pe[3];
 };
 
+// the chain from the joints' sines / cosines (split from the trigonometry so that a lane group can share ONE sincos per
+// lane instead of six per lane: atacom_kernels.h, group_sincos6)
 template <typename T>
-__device__ __forceinline__ void iiwa_fk(const T (&q)[6], IiwaKin<T>& k) {
+__device__ __forceinline__ void iiwa_chain(const T (&sn)[6], const T (&cs)[6], IiwaKin<T>& k) {
     // frame columns X, Y, Z of the current link
     T X[3] = {T(1), T(0), T(0)}, Y[3] = {T(0), T(1), T(0)}, Z[3] = {T(0), T(0), T(1)};
     T o[3] = {T(0), T(0), T(0)};
@@ -194,8 +196,7 @@ __device__ __forceinline__ void iiwa_fk(const T (&q)[6], IiwaKin<T>& k) {
             else if (kind[i] == 1) { nx[a] = -X[a]; ny[a] = Z[a]; nz[a] = Y[a]; }
             else { nx[a] = X[a]; ny[a] = Z[a]; nz[a] = -Y[a]; }
         }
-        T s, c;
-        num<T>::sincos(q[i], &s, &c);
+        const T s = sn[i], c = cs[i];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             X[a] = num<T>::fma(c, nx[a], s * ny[a]);
@@ -214,6 +215,13 @@ __device__ __forceinline__ void iiwa_fk(const T (&q)[6], IiwaKin<T>& k) {
         k.p7[a] = num<T>::fma(Y[a], T(0.081), o[a]);
         k.pe[a] = num<T>::fma(Y[a], T(0.081) + T(0.585), o[a]);
     }
+}
+template <typename T>
+__device__ __forceinline__ void iiwa_fk(const T (&q)[6], IiwaKin<T>& k) {
+    T sn[6], cs[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) num<T>::sincos(q[i], &sn[i], &cs[i]);
+    iiwa_chain(sn, cs, k);
 }
 
 // linear Jacobian column i of point p:  z_i x (p - o_i)
@@ -321,9 +329,8 @@ __device__ __forceinline__ void constraint_terms(Iiwa, const Params<T>& P, const
     }
 }
 template <typename T>
-__device__ __forceinline__ void constraint_fun(Iiwa, const Params<T>& P, const T (&q)[6], T (&fun)[12], T (&mxy)[2]) {
-    IiwaKin<T> k;
-    iiwa_fk(q, k);
+__device__ __forceinline__ void iiwa_fun_from_kin(const Params<T>& P, const IiwaKin<T>& k, const T (&q)[6], T (&fun)[12],
+                                                  T (&mxy)[2]) {
     const T xw = k.pe[0] + P.base_x, yw = k.pe[1] + P.base_y;
     fun[0] = k.pe[2] - P.ee_height;
     fun[1] = -xw - P.table_bx;
@@ -334,6 +341,12 @@ __device__ __forceinline__ void constraint_fun(Iiwa, const Params<T>& P, const T
 #pragma unroll
     for (int i = 0; i < 6; ++i) fun[6 + i] = num<T>::fma(q[i], q[i], -P.pos_limit[i] * P.pos_limit[i]);
     mxy[0] = xw; mxy[1] = yw;
+}
+template <typename T>
+__device__ __forceinline__ void constraint_fun(Iiwa, const Params<T>& P, const T (&q)[6], T (&fun)[12], T (&mxy)[2]) {
+    IiwaKin<T> k;
+    iiwa_fk(q, k);
+    iiwa_fun_from_kin(P, k, q, fun, mxy);
 }
 
 }  // namespace atacom

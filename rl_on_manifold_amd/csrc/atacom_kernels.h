@@ -397,6 +397,193 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
     }
 }
 
+// ------------------------------------------------------------------ the step prologue DISTRIBUTED over a lane group (iiwa)
+// Round 5.  With one environment per 8 lanes the prologue of a step -- kinematics, the three frame
+// Jacobians, bias terms, assembly of K J, the hoisted first reflector G(0), the pick of "my columns" -- was computed by
+// every lane of the group, bitwise identically: ~1.4 k of the ~10.4 k vector instructions a wave executes per step, all of
+// them 8-fold redundant.  Here the lanes share it the way the solver wants the result anyway (atacom_quad.h: column 0 of
+// K J replicated, column c >= 1 in lane c - 1):
+//   * trigonometry: lane l evaluates sincos(q_l) ONCE (instead of six per lane) and the group exchanges the twelve values
+//     by DPP broadcasts; the serial frame chain from them stays replicated (it does not split);
+//   * lane c - 1 computes Jacobian COLUMN c of the three frames from "its" joint frame (z_c, o_c: a one-hot blend of the
+//     replicated chain), i.e. its own column of K J for all twelve rows; column 0 (joint 1: the base's vertical axis) is cheap
+//     and stays replicated;
+//   * frame velocities J dq are group sums of the lanes' column terms (one DPP butterfly of six values) instead of 3 x 6
+//     replicated multiply-adds per frame;
+//   * G(0): row 0 of K J is gathered once (five broadcasts), the reflector generated replicated FROM THE SAME VALUES IN THE
+//     SAME ORDER as the replicated form (identical beta, tau, v); the five dense rows below take one butterfly, the six
+//     joint-limit rows (one entry each) need none; every lane then updates its own column.
+// Same arithmetic as constraint_terms + the assembly + G0PRE of env_step's replicated prologue, except for the summation
+// order of the frame velocities and of the reflector's row sums (float64 build: 1e-8 against the oracle like every
+// mapping).  bias_mode 0 (the reference's w x v) only: the exact-bias option keeps the replicated prologue.
+template <typename T, int LN>
+__device__ __forceinline__ void group_sincos6(const T (&q)[6], const T (&oh)[LN], T (&sn)[6], T (&cs)[6]) {
+#pragma clang fp contract(off)       // every multiply-add of the group prologue is written as an explicit fma: k_step, k_rollout and
+                                     // k_rollout_mlp must contract identically (their results are compared bit for bit)
+    static_assert(LN >= 6, "one joint per lane");
+    T qm = oh[0] * q[0];                                  // exact: the mask is 0 / 1 (lanes 6, 7: angle 0)
+#pragma unroll
+    for (int i = 1; i < 6; ++i) qm = num<T>::fma(oh[i], q[i], qm);
+    T sm, cm;
+    num<T>::sincos(qm, &sm, &cm);
+    static_for<0, 6>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        sn[i] = qbcast<i, LN>(sm);
+        cs[i] = qbcast<i, LN>(cm);
+    });
+}
+// linear Jacobian column of point p for the joint frame (z, o): z x (p - o)   (the arithmetic of jac_col, atacom_envs.h)
+template <typename T>
+__device__ __forceinline__ void cross_col(const T (&z)[3], const T (&o)[3], const T (&p)[3], T (&col)[3]) {
+#pragma clang fp contract(off)
+    const T rx = p[0] - o[0], ry = p[1] - o[1], rz = p[2] - o[2];
+    col[0] = num<T>::fma(z[1], rz, -(z[2] * ry));
+    col[1] = num<T>::fma(z[2], rx, -(z[0] * rz));
+    col[2] = num<T>::fma(z[0], ry, -(z[1] * rx));
+}
+// group sums of six values (LN = 8)
+template <typename T>
+__device__ __forceinline__ void group8_sum6(T& a, T& b, T& c, T& d, T& e, T& f) { osum_n(a, b, c, d, e, f); }
+
+// Outputs, in the layout the lane-group solver reads (env_step): A0[r] = column 0 of K J (replicated), Amy[r] = this lane's
+// column lq + 1 (zeros in lanes >= 5: their slot-0 columns are slack columns), yb = psi + Kc c0, the mallet position;
+// G0: rows as G(0) leaves them, row 0 of Amy = the reflector's entry, (g0_d, g0_tau) = its beta / tau.
+template <typename T, int LN, bool G0>
+__device__ __forceinline__ void iiwa_prepare_group(const Params<T>& P, const T (&qc)[6], const T (&dqc)[6], const int lq,
+                                                   T (&A0)[12], T (&Amy)[12], T (&yb)[12], T& g0_d, T& g0_tau, T& mx, T& my) {
+#pragma clang fp contract(off)       // see group_sincos6
+    static_assert(LN == 8, "written for one environment per 8 lanes");
+    constexpr int NQ = 6, NC = 12;
+    T oh[LN];
+#pragma unroll
+    for (int l = 0; l < LN; ++l) oh[l] = (lq == l) ? T(1) : T(0);
+    T sn[6], cs[6];
+    group_sincos6<T, LN>(qc, oh, sn, cs);
+    IiwaKin<T> k;
+    iiwa_chain(sn, cs, k);
+    // "my" joint c = lq + 1 (lanes 0..4): frame, velocity and limit term, one-hot over joints 1..5
+    T zc[3], oc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        T vz = oh[0] * k.z[1][a], vo = oh[0] * k.o[1][a];
+#pragma unroll
+        for (int j = 2; j < NQ; ++j) { vz = num<T>::fma(oh[j - 1], k.z[j][a], vz); vo = num<T>::fma(oh[j - 1], k.o[j][a], vo); }
+        zc[a] = vz; oc[a] = vo;
+    }
+    T dqm = oh[0] * dqc[1];
+#pragma unroll
+    for (int j = 2; j < NQ; ++j) dqm = num<T>::fma(oh[j - 1], dqc[j], dqm);
+    T Je[3], J7[3], Je0[3], J70[3], J40[3], J41[3];
+    cross_col(zc, oc, k.pe, Je);
+    cross_col(zc, oc, k.p7, J7);
+    jac_col(k, 0, k.pe, Je0);
+    jac_col(k, 0, k.p7, J70);
+    jac_col(k, 0, k.p4, J40);
+    jac_col(k, 1, k.p4, J41);          // link_4 moves with joints 1, 2 only (constraint_terms); both columns replicated
+    // frame velocities v = J dq: the lanes' column terms summed over the group, + column 0
+    T ve[3], v7[3], v4[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { ve[a] = Je[a] * dqm; v7[a] = J7[a] * dqm; }
+    group8_sum6(ve[0], ve[1], ve[2], v7[0], v7[1], v7[2]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        ve[a] = num<T>::fma(Je0[a], dqc[0], ve[a]);
+        v7[a] = num<T>::fma(J70[a], dqc[0], v7[a]);
+        v4[a] = num<T>::fma(J41[a], dqc[1], J40[a] * dqc[0]);
+    }
+    // angular velocities (frame_bias: fma chain over the joints in order); w4 is the prefix of w6
+    T w4[3] = {T(0), T(0), T(0)}, w6[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) w4[a] = num<T>::fma(k.z[i][a], dqc[i], w4[a]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) w6[a] = num<T>::fma(k.z[5][a], dqc[5], num<T>::fma(k.z[4][a], dqc[4], w4[a]));
+    // bias_mode 0: "classical acceleration" w x v (quirk Q2)
+    T ae[3];
+    ae[0] = num<T>::fma(w6[1], ve[2], -(w6[2] * ve[1]));
+    ae[1] = num<T>::fma(w6[2], ve[0], -(w6[0] * ve[2]));
+    ae[2] = num<T>::fma(w6[0], ve[1], -(w6[1] * ve[0]));
+    const T a4z = num<T>::fma(w4[0], v4[1], -(w4[1] * v4[0]));
+    const T a7z = num<T>::fma(w6[0], v7[1], -(w6[1] * v7[0]));
+    T fun[NC], bst[NC], jdq[NC], mxy[2];
+    iiwa_fun_from_kin(P, k, qc, fun, mxy);
+    mx = -(fun[1] + P.table_bx);            // mallet (= tip) xy, as env_step recovers it from the table rows
+    my = fun[3] + P.table_by;
+    bst[0] = ae[2];                                                        // iiwa_hit_atacom.py:84-91
+    bst[1] = -ae[0]; bst[2] = -ae[1]; bst[3] = ae[1]; bst[4] = -a4z; bst[5] = -a7z;          // :119-130
+    jdq[0] = ve[2]; jdq[1] = -ve[0]; jdq[2] = -ve[1]; jdq[3] = ve[1]; jdq[4] = -v4[2]; jdq[5] = -v7[2];
+    T d2q[NQ];                              // the joint-limit rows' one Jacobian entry, 2 q_i (:135-136)
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        d2q[i] = T(2) * qc[i];
+        bst[6 + i] = T(2) * dqc[i] * dqc[i];                               // :138-139
+        jdq[6 + i] = num<T>::fma(d2q[i], dqc[i], T(0));
+    }
+#pragma unroll
+    for (int r = 0; r < NC; ++r) {
+        const T psi = num<T>::fma(P.K[r], bst[r], jdq[r]);                 // constraints.py:42-43
+        const T c0 = num<T>::fma(P.K[r], jdq[r], fun[r]);                  // constraints.py:33-37
+        yb[r] = num<T>::fma(P.Kc[r], c0, psi);
+    }
+    // K J: column 0 replicated, my column (the "+ 0" of env_step's assembly: no -0 entries)
+    A0[0] = num<T>::fma(P.K[0], Je0[2], T(0));
+    A0[1] = num<T>::fma(P.K[1], -Je0[0], T(0));
+    A0[2] = num<T>::fma(P.K[2], -Je0[1], T(0));
+    A0[3] = num<T>::fma(P.K[3], Je0[1], T(0));
+    A0[4] = num<T>::fma(P.K[4], -J40[2], T(0));
+    A0[5] = num<T>::fma(P.K[5], -J70[2], T(0));
+    A0[6] = num<T>::fma(P.K[6], d2q[0], T(0));
+#pragma unroll
+    for (int r = 7; r < NC; ++r) A0[r] = T(0);
+    Amy[0] = num<T>::fma(P.K[0], Je[2], T(0));
+    Amy[1] = num<T>::fma(P.K[1], -Je[0], T(0));
+    Amy[2] = num<T>::fma(P.K[2], -Je[1], T(0));
+    Amy[3] = num<T>::fma(P.K[3], Je[1], T(0));
+    Amy[4] = (lq == 0) ? num<T>::fma(P.K[4], -J41[2], T(0)) : T(0);        // row 4: joints 3..6 do not move link_4
+    Amy[5] = num<T>::fma(P.K[5], -J7[2], T(0));
+    Amy[6] = T(0);
+    T dg[NQ];                               // diagonal entries K (2 q_i) of the joint-limit rows, replicated
+#pragma unroll
+    for (int i = 1; i < NQ; ++i) {
+        dg[i] = num<T>::fma(P.K[6 + i], d2q[i], T(0));
+        Amy[6 + i] = (lq == i - 1) ? dg[i] : T(0);
+    }
+    if constexpr (G0) {
+        // G(0): row 0 = [A0[0] | A[0][1..5]]; gathered so that every lane generates the reflector from the same values in the
+        // order of the replicated prologue
+        T r0[NQ], v[NQ];
+        static_for<1, NQ>([&](auto cc) { constexpr int c = decltype(cc)::value; r0[c] = qbcast<c - 1, LN>(Amy[0]); });
+        T ss = T(0);
+#pragma unroll
+        for (int c = 1; c < NQ; ++c) ss = num<T>::fma(r0[c], r0[c], ss);
+        T beta;
+        const T sc = larfg_scale(A0[0], ss, beta, g0_tau);
+        g0_d = beta;
+#pragma unroll
+        for (int c = 1; c < NQ; ++c) v[c] = r0[c] * sc;
+        const T vmy = (lq < NQ - 1) ? Amy[0] * sc : T(0);
+        // dense rows 1..5: w_r = tau (A[r][0] + sum_c A[r][c] v_c) -- the column terms summed over the group
+        T wp[6];
+#pragma unroll
+        for (int r = 1; r < 6; ++r) wp[r] = Amy[r] * vmy;
+        wp[0] = T(0);
+        group8_sum6(wp[0], wp[1], wp[2], wp[3], wp[4], wp[5]);
+        T w[NC];
+#pragma unroll
+        for (int r = 1; r < 6; ++r) w[r] = (A0[r] + wp[r]) * g0_tau;
+        w[6] = A0[6] * g0_tau;                                               // joint-limit rows: one entry each
+#pragma unroll
+        for (int i = 1; i < NQ; ++i) w[6 + i] = num<T>::fma(dg[i], v[i], T(0)) * g0_tau;
+#pragma unroll
+        for (int r = 1; r < NC; ++r) {
+            A0[r] -= w[r];
+            Amy[r] = num<T>::fma(-w[r], vmy, Amy[r]);
+        }
+        Amy[0] = vmy;
+    }
+}
+
 // ------------------------------------------------------------------ one env step (A1, A2, A13-A15)
 // LANES = 1: one environment per lane (atacom_linalg.h).  LANES = 4: one environment per DPP quad -- the
 // null-space solve is column-split over the quad (atacom_quad.h), everything else is computed redundantly
@@ -462,6 +649,11 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
     // CANON, LANES > 1 (third form, atacom_chart_group.h): the lane's own columns / rows of A, built with A
     constexpr bool CANON3 = CANON && LANES > 1 && (ATACOM_CHART_FORM == 3);
     [[maybe_unused]] ChartPre<T, E, LGC> cpre;
+    // the prologue shared by the lanes of a group instead of replicated in each (iiwa_prepare_group above; round 5)
+#ifndef ATACOM_GROUP_PRE
+#define ATACOM_GROUP_PRE 1          // -DATACOM_GROUP_PRE=0: the A/B build with the replicated prologue
+#endif
+    constexpr bool GROUP_PRE = ATACOM_GROUP_PRE && E::ID == 2 && LANES == 8 && !CANON && E::MODE == 0 && !DYN;
     auto prepare = [&](int sub) {
 #pragma unroll
             for (int i = 0; i < NQ; ++i) { qc[i] = st.q[i]; dqc[i] = st.dq[i]; }
@@ -475,9 +667,27 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
             }
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
-                // lo <= up always (K_q, vel_max > 0 and both are clamped into [-acc_max, acc_max])
-                tup[i] = num<T>::max(num<T>::min(P.acc_max[i], -P.Kq[i] * (dqc[i] - P.vel_max[i])), -P.acc_max[i]);
-                tlo[i] = num<T>::min(num<T>::max(-P.acc_max[i], -P.Kq[i] * (dqc[i] + P.vel_max[i])), P.acc_max[i]);
+                // lo <= up always (K_q, vel_max > 0 and both are clamped into [-acc_max, acc_max]).  max(min(a, x), -a) and
+                // min(max(-a, x), a) are the same clamp of x into [-a, a] (a = acc_max > 0): one v_med3_f32 each instead
+                // of a min / max pair with its canonicalising v_max x, x in front
+                tup[i] = num<T>::clamp(-P.Kq[i] * (dqc[i] - P.vel_max[i]), -P.acc_max[i], P.acc_max[i]);
+                tlo[i] = num<T>::clamp(-P.Kq[i] * (dqc[i] + P.vel_max[i]), -P.acc_max[i], P.acc_max[i]);
+            }
+            if constexpr (GROUP_PRE) {
+                if (P.bias_mode == 0) {         // launch-uniform; the exact-bias option keeps the replicated prologue below
+                    ATACOM_MARK("PRE_group");
+                    T A0[NC], Amy[NC], mx, my;
+                    iiwa_prepare_group<T, LANES, G0PRE>(P, qc, dqc, lq, A0, Amy, yb, g0_d, g0_tau, mx, my);
+                    if (sub == 0) { m0x = mx; m0y = my; }
+#pragma unroll
+                    for (int r = 0; r < NC; ++r) {
+                        A[r][0] = A0[r];
+                        Aq[r][0] = Amy[r];
+#pragma unroll
+                        for (int sl = 1; sl < SQ; ++sl) Aq[r][sl] = T(0);       // columns 9.. are slack columns
+                    }
+                    return;
+                }
             }
             T fun[NC], J[NC][NQ], bst[NC];
             ATACOM_MARK("PRE_terms");
@@ -731,7 +941,17 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
         out.absorbing = false;                                                              // :67
     } else {
         T fun[NC], mxy[2];
-        constraint_fun(E{}, P, st.q, fun, mxy);
+        if constexpr (GROUP_PRE) {              // post-step kinematics: one sincos per lane, shared by the group
+            T oh[LANES], sn[NQ], cs[NQ];
+#pragma unroll
+            for (int l = 0; l < LANES; ++l) oh[l] = (lq == l) ? T(1) : T(0);
+            group_sincos6<T, LANES>(st.q, oh, sn, cs);
+            IiwaKin<T> kin;
+            iiwa_chain(sn, cs, kin);
+            iiwa_fun_from_kin(P, kin, st.q, fun, mxy);
+        } else {
+            constraint_fun(E{}, P, st.q, fun, mxy);
+        }
         // ---- puck (row N1): the arm is kinematic w.r.t. the puck, so the puck's sub-steps run after the arm's,
         // against a mallet moving uniformly from (m0x, m0y) to mxy over the env step.  Frictionless disc,
         // impulse + push-out at the mallet, elastic rims, open goal mouths (env_hitting.py:44-45).

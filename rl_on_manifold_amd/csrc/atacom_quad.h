@@ -226,6 +226,47 @@ __device__ __forceinline__ void qsum_pairs(vec2<T> (&w)[CNT]) {
 #pragma unroll
     for (int j = 0; j < CNT; ++j) w[j] = vec2<T>{h[2 * j], h[2 * j + 1]};
 }
+// ---- "split" group sums for 8 lanes (round 5): 2 H values of which THIS lane's half of the group reduces only H.
+// The P-application sums the K + 1 vectors [nb_0 .. nb_{K-1}, x] over the group.  The vectors are interchangeable, so the
+// upper half of the group (lanes 4..7) keeps them in ROTATED register order: its physical slot q holds vector (q + H) mod 2H.
+// With X = slots 0..H-1 and Y = slots H..2H-1 one level across the halves, X_k += mirror(Y_k), then hands every half the
+// partial sums of "its" H vectors over both halves' columns (lower half: vectors 0..H-1, upper half: H..2H-1 -- the partner's
+// Y_k is the same vector as my X_k); two quad levels finish them, and Y_k = mirror(X_k) returns the other H totals:
+// 4 H cross-lane instructions instead of the butterfly's 6 H, the same bits in all eight lanes (a vector's total is formed
+// in one half and copied).  h[0..2H-1] in, totals out (in the lane's own physical order).
+#define ATACOM_DPP_HM " row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void split_sum(float (&h)[6]) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %3, %0" ATACOM_DPP_HM "v_add_f32_dpp %1, %4, %1" ATACOM_DPP_HM "v_add_f32_dpp %2, %5, %2" ATACOM_DPP_HM
+        "v_add_f32_dpp %0, %0, %0" ATACOM_DPP_X1 "v_add_f32_dpp %1, %1, %1" ATACOM_DPP_X1 "v_add_f32_dpp %2, %2, %2" ATACOM_DPP_X1
+        "v_add_f32_dpp %0, %0, %0" ATACOM_DPP_X2 "v_add_f32_dpp %1, %1, %1" ATACOM_DPP_X2 "v_add_f32_dpp %2, %2, %2" ATACOM_DPP_X2
+        "v_mov_b32_dpp %3, %0" ATACOM_DPP_HM "v_mov_b32_dpp %4, %1" ATACOM_DPP_HM "v_mov_b32_dpp %5, %2" ATACOM_DPP_HM
+        : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]), "+v"(h[4]), "+v"(h[5]));
+}
+__device__ __forceinline__ void split_sum(float (&h)[4]) {
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %2, %0" ATACOM_DPP_HM "v_add_f32_dpp %1, %3, %1" ATACOM_DPP_HM "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0" ATACOM_DPP_X1 "v_add_f32_dpp %1, %1, %1" ATACOM_DPP_X1 "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0" ATACOM_DPP_X2 "v_add_f32_dpp %1, %1, %1" ATACOM_DPP_X2 "s_nop 0\n\t"
+        "v_mov_b32_dpp %2, %0" ATACOM_DPP_HM "v_mov_b32_dpp %3, %1" ATACOM_DPP_HM
+        : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]), "+v"(h[3]));
+}
+template <int H2>
+__device__ __forceinline__ void split_sum(double (&h)[H2]) {
+    constexpr int H = H2 / 2;
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        double x = h[k] + dpp_mov<DPP_ROW_HALF_MIRROR>(h[H + k]);
+        x = x + dpp_mov<0xB1>(x);
+        x = x + dpp_mov<0x4E>(x);
+        h[k] = x;
+        h[H + k] = dpp_mov<DPP_ROW_HALF_MIRROR>(x);
+    }
+}
+#ifndef ATACOM_P_RELABEL
+#define ATACOM_P_RELABEL 1          // -DATACOM_P_RELABEL=0: the A/B build with the butterfly sums in the P-application
+#endif
+
 template <int O, int LN = 4, typename T> __device__ __forceinline__ vec2<T> qbcast2(vec2<T> v) {
     return vec2<T>{qbcast<O, LN>(v.x), qbcast<O, LN>(v.y)};
 }
@@ -414,7 +455,12 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, A0F&& a0ge
     T z[M];
     bidiag_forward_solve<T, M>(d, e, [&](int i) { return y2[i / 2][i % 2]; }, z);
     // [nb_0 .. nb_{K-1}, x] as pairs over the vector index; coordinate 0 replicated (nx0), coordinates >= 1 split
+    // RELABEL (8 lanes, K + 1 even): the upper half of the group holds vector (q + H) mod 2H in physical slot q (split_sum)
+    constexpr bool RELABEL = ATACOM_P_RELABEL && LN == 8 && (K + 1) % 2 == 0 && K + 1 >= 4 && K + 1 <= 6;
+    constexpr int HV = (K + 1) / 2;
+    const bool hf = RELABEL && (lq >= LN / 2);
     V2 nx[S][KP], nx0[KP];
+    if constexpr (!RELABEL) {
 #pragma unroll
     for (int j = 0; j < KP; ++j) nx0[j] = V2{(2 * j == K) ? z[0] : T(0), (2 * j + 1 == K) ? z[0] : T(0)};
 #pragma unroll
@@ -429,6 +475,45 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, A0F&& a0ge
                                : ((k == K) ? pick4<T, M, LN>(z, LN * s + 1, lq) : T(0));
             }
             nx[s][j] = V2{h[0], h[1]};
+        }
+    }
+    } else {
+        // physical slot q: vector q in lanes 0..3, vector (q + HV) mod (K + 1) in lanes 4..7.  The unit entry of null vector k
+        // sits at coordinate M + k, i.e. in ONE known lane: the test below is a compile-time constant per (slot, lane half)
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            T h[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int q = 2 * j + t;
+                h[t] = (q == K) ? (hf ? T(0) : z[0]) : (((q + HV) % (K + 1) == K) ? (hf ? z[0] : T(0)) : T(0));
+            }
+            nx0[j] = V2{h[0], h[1]};
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const T zv = pick4<T, M, LN>(z, LN * s + 1, lq);
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                T h[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int q = 2 * j + t;
+                    T v = T(0);
+#pragma unroll
+                    for (int up = 0; up < 2; ++up) {                   // the vector this slot holds in the lower / upper half
+                        const int k = up ? (q + HV) % (K + 1) : q;
+                        if (k < K) {
+                            const int c = M + k, own = (c - 1) % LN;       // coordinate of the unit entry, its lane
+                            if ((c - 1) / LN == s && (own >= LN / 2) == (up == 1)) v = (lq == own) ? T(1) : v;
+                        } else {
+                            v = (hf == (up == 1)) ? zv : v;
+                        }
+                    }
+                    h[t] = v;
+                }
+                nx[s][j] = V2{h[0], h[1]};
+            }
         }
     }
     // ---- [nb | x] <- G(1) ... G(M) [nb | x]
@@ -450,7 +535,17 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, A0F&& a0ge
 #pragma unroll
                 for (int s = s0 + 1; s < S; ++s) w[j] = fma2(splat2(vrow[s]), nx[s][ja + j], w[j]);
             }
-            qsum_pairs<CNT, T, LN>(w);
+            if constexpr (RELABEL) {
+                static_assert(!RELABEL || CNT == KP, "all K + 1 vectors in one reduction");
+                T h[2 * CNT];
+#pragma unroll
+                for (int j = 0; j < CNT; ++j) { h[2 * j] = w[j].x; h[2 * j + 1] = w[j].y; }
+                split_sum(h);
+#pragma unroll
+                for (int j = 0; j < CNT; ++j) w[j] = V2{h[2 * j], h[2 * j + 1]};
+            } else {
+                qsum_pairs<CNT, T, LN>(w);
+            }
 #pragma unroll
             for (int j = 0; j < CNT; ++j) {
                 if constexpr (first) w[j] += nx0[ja + j];
@@ -462,6 +557,7 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, A0F&& a0ge
         });
     });
     ATACOM_MARK("P_done");
+    if constexpr (!RELABEL) {
     x0 = nx0[K / 2][K % 2];
 #pragma unroll
     for (int k = 0; k < K; ++k) nb0[k] = nx0[k / 2][k % 2];
@@ -470,6 +566,23 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, A0F&& a0ge
         x[s] = nx[s][K / 2][K % 2];
 #pragma unroll
         for (int k = 0; k < K; ++k) nb[s][k] = nx[s][k / 2][k % 2];
+    }
+    } else {
+        // back to the vectors' own order: vector k sits in slot k (lanes 0..3) or (k + HV) mod (K + 1) (lanes 4..7)
+        auto at = [&](const V2 (&v)[KP], int k) -> T {
+            const int qu = (k + HV) % (K + 1);
+            const T lo = v[k / 2][k % 2], up = v[qu / 2][qu % 2];
+            return hf ? up : lo;
+        };
+        x0 = at(nx0, K);
+#pragma unroll
+        for (int k = 0; k < K; ++k) nb0[k] = at(nx0, k);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            x[s] = at(nx[s], K);
+#pragma unroll
+            for (int k = 0; k < K; ++k) nb[s][k] = at(nx[s], k);
+        }
     }
 }
 

@@ -1,0 +1,62 @@
+"""Tuning / audit helper (not a pytest file): where does the largest constraint value of a free-running float32 rollout come
+from?  Replays shard R of the config-5 rehearsal (tests/test_gpu_rollout.py: bench.make_env, seed 1234 + R) step by step,
+finds the (step, environment) of the largest c = max(|f|, g), then teacher-forces the float64 device kernels and the float64
+oracle through the steps before it FROM THE FLOAT32 DEVICE'S OWN STATES: if they produce the same violation from the same
+state, it is the reference algorithm's (the rref tolerance branch leaks), not the kernel's.
+    python tests/gpu_cmax_probe.py [R] [LIB...]"""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+import bench
+from rl_on_manifold_amd import BatchedAtacomEnv, constraint_terms
+from oracle import atacom_scalar as osc, atacom_batched as ob
+DEV = 'cuda:0'
+B, T = 8192, 120
+gen = torch.Generator(device=DEV); gen.manual_seed(1234 + R)
+env, init, _ = bench.make_env('iiwa', B, torch.device(DEV), gen)
+acts = torch.rand((T, B, 5), device=DEV, generator=gen) * 2 - 1
+print('lanes', env.lanes_per_env, env.rollout_lanes_per_env)
+
+
+def cvals(q):
+    fun, _, _ = constraint_terms('iiwa', q, torch.zeros_like(q))
+    return torch.maximum(fun[:, 0].abs(), fun[:, 1:].max(1).values)
+
+states, cs = [], []
+for t in range(T):
+    states.append(env.get_state().clone())
+    env.step(acts[t])
+    cs.append(cvals(env.get_state()[:, :6]))
+cs = torch.stack(cs)                                  # [T, B]
+print('device stats', env.get_constraints_logs(), 'c from states max', float(cs.max()))
+flat = int(cs.argmax()); t_star, b_star = flat // B, flat % B
+print('largest c %.5f at step %d env %d; that env over the steps before: %s' % (
+    float(cs[t_star, b_star]), t_star, b_star, ' '.join('%.4f' % float(x) for x in cs[max(0, t_star - 8):t_star + 3, b_star])))
+top = torch.topk(cs.max(0).values, 5)
+print('five worst environments: ' + ', '.join('env %d c %.4f' % (int(i), float(v)) for v, i in zip(top.values, top.indices)))
+# teacher-forced comparison on the worst environment, from the float32 device's own states
+spec = osc.iiwa_spec()
+e64 = BatchedAtacomEnv('iiwa', 1, device=DEV, dtype=torch.float64, auto_reset=True, lanes_per_env=env.lanes_per_env)
+nq, ng = 6, 11
+for t in range(max(0, t_star - 6), t_star + 1):
+    st = states[t][b_star:b_star + 1].double()
+    a = acts[t][b_star:b_star + 1].double()
+    e64.set_state(st)
+    e64.step(a)
+    q64 = e64.get_state()[:, :6]
+    o = ob.BatchedAtacomEnv(spec, 1, init_q=st[:, :nq].cpu().numpy())
+    s_np = st.cpu().numpy()
+    o.set_state(s_np[:, :nq], s_np[:, nq:2 * nq], s_np[:, 2 * nq:2 * nq + ng], s_np[:, 2 * nq + ng:2 * nq + ng + 6])
+    o.t[:] = int(s_np[0, -1])
+    o.track_margins(True)
+    o.step(a.cpu().numpy())
+    qo = torch.tensor(o.q, device=DEV)
+    q32 = (states[t + 1] if t + 1 < T else env.get_state())[b_star:b_star + 1, :6].double()
+    print('step %3d: c after the step  device f32 %.5f | device f64 from the same state %.5f | oracle f64 %.5f   '
+          '|q32 - oracle| %.2e  |q64 - oracle| %.2e   oracle: rref skipped %s, decision margin %.2e, cond %.1e, slack min %.3e'
+          % (t, float(cvals(q32.float())), float(cvals(q64.float())), float(cvals(qo.float())),
+             float((q32 - qo).abs().max()), float((q64 - qo).abs().max()), bool(o.chart_skipped[0]),
+             float(o.decision_margin[0]), float(o.cond_number[0]), float(s_np[0, 2 * nq:2 * nq + ng].min())))

@@ -885,7 +885,12 @@ def test_host_side_error_paths_and_multiple_handles():
         del os.environ['ATACOM_CALIBRATE']
     e = BatchedAtacomEnv('iiwa', 16384, device=DEV)
     assert (e.lanes_per_env, e.rollout_lanes_per_env) == (4, 4)
-    assert BatchedAtacomEnv('iiwa', 64, device=DEV, dtype=torch.float64).lanes_per_env == 1
+    # float64: one environment per lane, except iiwa up to 8192 environments (8 lanes: 30 % faster, profiles/r05_f64_lanes.log)
+    assert BatchedAtacomEnv('iiwa', 64, device=DEV, dtype=torch.float64).lanes_per_env == 8
+    assert BatchedAtacomEnv('iiwa', 16384, device=DEV, dtype=torch.float64).lanes_per_env == 1
+    assert BatchedAtacomEnv('planar', 64, device=DEV, dtype=torch.float64).lanes_per_env == 1
+    p8 = BatchedAtacomEnv('planar', 8192, device=DEV)
+    assert (p8.lanes_per_env, p8.rollout_lanes_per_env) == (4, 8)          # planar: T-step kernels on 8 lanes (round 5)
     a = torch.full((96, 3), 0.3, device=DEV)
     side = torch.cuda.Stream(device=DEV)
     with torch.cuda.stream(side):                                 # launches go to the caller's current stream
