@@ -21,6 +21,12 @@
 #pragma once
 #include "atacom_envs.h"
 #include "atacom_iiwa_inertia.h"
+#include "atacom_dynamics_link.h"
+// round 5: the kernels evaluate the recursions in LINK coordinates (atacom_dynamics_link.h); the world-coordinate forms below
+// stay as the A/B build (-DATACOM_DYN_LINK=0) and as the readable statement of the same equations
+#ifndef ATACOM_DYN_LINK
+#define ATACOM_DYN_LINK 1
+#endif
 
 namespace atacom {
 

@@ -48,11 +48,14 @@ template <int LANES> constexpr int BLOCK = (LANES > 1) ? ATACOM_BLOCK_GROUP : 64
 // Field numbering is unchanged from the plane era ("plane" = field index); pl() maps it to the buffer.
 template <typename E>
 struct Planes {
-    static constexpr int Q = 0, DQ = Q + E::NQ, S = DQ + E::NQ, PUCK = S + E::NG, RHIT = PUCK + 6, VHX = RHIT + 1,
-                         SSUM = VHX + 1, SCMAX = SSUM + 1, SDQMAX = SCMAX + 1, HOT = SDQMAX + 1,
+    // (round 5: environments without a puck -- the circle family -- no longer carry the eight puck / hit fields and the six
+    // stored puck values: their step moved 186 bytes per environment against 60 algorithmic, profiles/r05_pmc_summary.md)
+    static constexpr int NP = E::PUCK ? 6 : 0, NH = E::PUCK ? 1 : 0;
+    static constexpr int Q = 0, DQ = Q + E::NQ, S = DQ + E::NQ, PUCK = S + E::NG, RHIT = PUCK + NP, VHX = RHIT + NH,
+                         SSUM = VHX + NH, SCMAX = SSUM + 1, SDQMAX = SCMAX + 1, HOT = SDQMAX + 1,
                          IQ = HOT, IDQ = IQ + E::NQ, IS = IDQ + E::NQ, IPUCK = IS + E::NG,
                          // row N4 (iiwa): the three servo joints of the rigid-body mode, positions then velocities
-                         QX = IPUCK + 6, DQX = QX + 3, AUX_END = (E::ID == 2) ? DQX + 3 : QX,
+                         QX = IPUCK + NP, DQX = QX + 3, AUX_END = (E::ID == 2) ? DQX + 3 : QX,
                          // obs_delay: the low-pass state of the observation's velocities, puck (3) then joints (NQ)
                          FV = AUX_END, COUNT = E::PUCK ? FV + 3 + E::NQ : FV;
     static constexpr int HOT_LD = (HOT + 3) / 4 * 4, COLD_LD = (COUNT - HOT + 3) / 4 * 4;
@@ -338,9 +341,7 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
     for (int i = 0; i < 6; ++i) { q9[i] = st.q[i]; dq9[i] = st.dq[i]; }
 #pragma unroll
     for (int i = 0; i < 3; ++i) { q9[6 + i] = st.qx[i]; dq9[6 + i] = st.dqx[i]; }
-    Chain9<T> ch;
     ATACOM_MARK("DYN_chain"); ATACOM_PHASE();
-    iiwa_chain9(q9, ch);
     // The equation of motion is linear in the accelerations, tau = M(q) ddq + h(q, dq), so ONE recursive Newton-Euler
     // pass (h: all accelerations zero) and the mass-matrix rows the step needs anyway replace the two passes of the literal
     // formulation (inverse dynamics of the planned acceleration; bias with the servo joints' accelerations):
@@ -349,13 +350,29 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
     T zero9[9], h9[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) zero9[i] = T(0);
+    T Ml[9][6], Mss[3];                             // rows 0..5: M_cc (lower triangle); rows 6..8: M_sc = M_cs^T
+    T z6[3], z7[3], y7[3];                          // world axes behind the servo set-points
+#if ATACOM_DYN_LINK
+    lk::Trig9<T> tg;
+    lk::trig9(q9, tg);
+    ATACOM_MARK("DYN_rnea"); ATACOM_PHASE();
+    lk::rnea9<T, true>(tg, dq9, zero9, h9);
+    ATACOM_MARK("DYN_crba"); ATACOM_PHASE();
+    lk::crba<T, 6, 9>(tg, Ml, Mss);
+    ATACOM_MARK("DYN_servo"); ATACOM_PHASE();
+    lk::servo_axes(tg, z6, z7, y7);
+#else
+    Chain9<T> ch;
+    iiwa_chain9(q9, ch);
     ATACOM_MARK("DYN_rnea"); ATACOM_PHASE();
     rnea9<T, true>(ch, dq9, zero9, h9);
     ATACOM_MARK("DYN_crba"); ATACOM_PHASE();
-    T Ml[9][6], Mss[3];                             // rows 0..5: M_cc (lower triangle); rows 6..8: M_sc = M_cs^T
     crba<T, 6, 9>(ch, Ml, Mss);
     ATACOM_MARK("DYN_servo"); ATACOM_PHASE();
-    const T tgt[3] = {joint7_target(ch.a[5], ch.a[6], st.qx[0]), universal_target(ch.a[6], ch.a[7]), T(0)};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { z6[d] = ch.a[5][d]; z7[d] = ch.a[6][d]; y7[d] = ch.a[7][d]; }
+#endif
+    const T tgt[3] = {joint7_target(z6, z7, st.qx[0]), universal_target(z7, y7), T(0)};
     constexpr T vmax[3] = {T(1.5 * 2.356194490192345), T(1.5 * 3.1415926), T(1.5 * 3.1415926)};     // urdf:297,384,397
     constexpr T effort_s[3] = {T(40), T(10), T(10)};                                                // urdf:297,384,400
     T dds[3];
@@ -1443,8 +1460,10 @@ __global__ void k_fill_init(int B, T* __restrict__ f, int* __restrict__ ip, cons
     if (b >= B) return;
 #pragma unroll
     for (int i = 0; i < E::NQ; ++i) { pl<E>(f, L::IQ + i, B, b) = row[i]; pl<E>(f, L::IDQ + i, B, b) = row[E::NQ + i]; }
+    if (E::PUCK) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) pl<E>(f, L::IPUCK + i, B, b) = row[2 * E::NQ + i];
+        for (int i = 0; i < 6; ++i) pl<E>(f, L::IPUCK + i, B, b) = row[2 * E::NQ + i];
+    }
 }
 
 template <typename T, typename E>
@@ -1588,14 +1607,21 @@ __global__ void __launch_bounds__(WAVE) k_inverse_dynamics(int n, const T* __res
     T q9[9], dq9[9], dd9[9], t9[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) { q9[i] = q[(size_t)b * 9 + i]; dq9[i] = dq[(size_t)b * 9 + i]; dd9[i] = ddq[(size_t)b * 9 + i]; }
+    T Ml[9][9];
+#if ATACOM_DYN_LINK
+    lk::Trig9<T> tg;
+    lk::trig9(q9, tg);
+    lk::rnea9(tg, dq9, dd9, t9);
+    if (M) lk::crba<T, 9>(tg, Ml);
+#else
     Chain9<T> ch;
     iiwa_chain9(q9, ch);
     rnea9(ch, dq9, dd9, t9);
+    if (M) crba<T, 9>(ch, Ml);
+#endif
 #pragma unroll
     for (int i = 0; i < 9; ++i) tau[(size_t)b * 9 + i] = t9[i];
     if (M) {
-        T Ml[9][9];
-        crba<T, 9>(ch, Ml);
 #pragma unroll
         for (int i = 0; i < 9; ++i)
 #pragma unroll
@@ -1614,14 +1640,21 @@ __global__ void __launch_bounds__(WAVE) k_forward_dynamics(int n, const T* __res
         q9[i] = q[(size_t)b * 9 + i]; dq9[i] = dq[(size_t)b * 9 + i];
         dd9[i] = (i >= 6 && ddq_aux) ? ddq_aux[(size_t)b * 3 + (i >= 6 ? i - 6 : 0)] : T(0);
     }
+    T rhs[6], Ml[6][6];
+#if ATACOM_DYN_LINK
+    lk::Trig9<T> tg;
+    lk::trig9(q9, tg);
+    lk::rnea9(tg, dq9, dd9, bias);
+    lk::crba<T, 6>(tg, Ml);
+#else
     Chain9<T> ch;
     iiwa_chain9(q9, ch);
     rnea9(ch, dq9, dd9, bias);
-    T rhs[6], Ml[6][6];
+    crba<T, 6>(ch, Ml);
+#endif
 #pragma unroll
     for (int i = 0; i < 6; ++i)
         rhs[i] = tau6[(size_t)b * 6 + i] - bias[i] - (use_damping ? (T)iiwa_body::DAMPING[i] * dq9[i] : T(0));
-    crba<T, 6>(ch, Ml);
     chol_solve<T, 6>(Ml, rhs);
 #pragma unroll
     for (int i = 0; i < 6; ++i) ddq6[(size_t)b * 6 + i] = rhs[i];
