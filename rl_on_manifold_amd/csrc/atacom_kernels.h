@@ -22,8 +22,8 @@ namespace atacom {
 constexpr int WAVE = 64;
 // rigid-body kernels: park the held solver state in LDS across the dynamics (env_step); -DATACOM_DYN_PARK=0: the A/B build
 #ifndef ATACOM_DYN_PARK
-#define ATACOM_DYN_PARK 1
-#endif
+#define ATACOM_DYN_PARK 0           // round 5: off -- with the dynamics in link coordinates (atacom_dynamics_link.h) the quad kernels
+#endif                              // fit without it (no scratch, 130 AGPRs) and run 42.7 instead of 45.6 us per step
 // threads per workgroup of the step / rollout kernels: the quad mapping runs 2.7 % faster with four waves per
 // workgroup (one per SIMD of a CU, sharing the instruction cache), the lane mapping with one (measured, profiles/)
 #ifndef ATACOM_BLOCK_GROUP
@@ -333,15 +333,23 @@ __device__ __forceinline__ void reset_env(const Params<T>& P, const Ref& ref, En
 //           dynamics_mode 2: for [ddq, dds] -- the controller knows what the servo joints are about to do (feed-forward
 //           of their reaction on the arm; NOT what the reference computes);
 //   ddq   = M_aa^-1 (tau - rnea_a(q, dq, [0; dds]) - D_a dq_a)       (hybrid forward dynamics, URDF joint damping).
-template <typename T, typename E>
+// LINK: the recursions in link coordinates (atacom_dynamics_link.h, round 5) or in world coordinates (atacom_dynamics.h).
+template <typename T, typename E, bool LINK = true>
 __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<T, E>& st, T (&ddq)[E::NQ]) {
     static_assert(E::NQ == 6, "iiwa only");
+    // phase boundaries (scheduling barriers) belong to the world-coordinate form, whose three passes together overflow the
+    // register file when interleaved; around the link-coordinate form they only pin the allocator: with them the lane-mapped
+    // single-step kernel takes 76 scratch accesses INSIDE THE SOLVER block (73 -> 83 us per step), without them none
+#ifndef ATACOM_LK_PHASE
+#define ATACOM_LK_PHASE 0
+#endif
+    auto phase = [] { if constexpr (!(LINK && ATACOM_DYN_LINK) || ATACOM_LK_PHASE) ATACOM_PHASE(); };
     T q9[9], dq9[9];
 #pragma unroll
     for (int i = 0; i < 6; ++i) { q9[i] = st.q[i]; dq9[i] = st.dq[i]; }
 #pragma unroll
     for (int i = 0; i < 3; ++i) { q9[6 + i] = st.qx[i]; dq9[6 + i] = st.dqx[i]; }
-    ATACOM_MARK("DYN_chain"); ATACOM_PHASE();
+    ATACOM_MARK("DYN_chain"); phase();
     // The equation of motion is linear in the accelerations, tau = M(q) ddq + h(q, dq), so ONE recursive Newton-Euler
     // pass (h: all accelerations zero) and the mass-matrix rows the step needs anyway replace the two passes of the literal
     // formulation (inverse dynamics of the planned acceleration; bias with the servo joints' accelerations):
@@ -352,26 +360,26 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
     for (int i = 0; i < 9; ++i) zero9[i] = T(0);
     T Ml[9][6], Mss[3];                             // rows 0..5: M_cc (lower triangle); rows 6..8: M_sc = M_cs^T
     T z6[3], z7[3], y7[3];                          // world axes behind the servo set-points
-#if ATACOM_DYN_LINK
-    lk::Trig9<T> tg;
-    lk::trig9(q9, tg);
-    ATACOM_MARK("DYN_rnea"); ATACOM_PHASE();
-    lk::rnea9<T, true>(tg, dq9, zero9, h9);
-    ATACOM_MARK("DYN_crba"); ATACOM_PHASE();
-    lk::crba<T, 6, 9>(tg, Ml, Mss);
-    ATACOM_MARK("DYN_servo"); ATACOM_PHASE();
-    lk::servo_axes(tg, z6, z7, y7);
-#else
-    Chain9<T> ch;
-    iiwa_chain9(q9, ch);
-    ATACOM_MARK("DYN_rnea"); ATACOM_PHASE();
-    rnea9<T, true>(ch, dq9, zero9, h9);
-    ATACOM_MARK("DYN_crba"); ATACOM_PHASE();
-    crba<T, 6, 9>(ch, Ml, Mss);
-    ATACOM_MARK("DYN_servo"); ATACOM_PHASE();
+    if constexpr (LINK && ATACOM_DYN_LINK) {
+        lk::Trig9<T> tg;
+        lk::trig9(q9, tg);
+        ATACOM_MARK("DYN_rnea"); phase();
+        lk::rnea9<T, true>(tg, dq9, zero9, h9);
+        ATACOM_MARK("DYN_crba"); phase();
+        lk::crba<T, 6, 9>(tg, Ml, Mss);
+        ATACOM_MARK("DYN_servo"); phase();
+        lk::servo_axes(tg, z6, z7, y7);
+    } else {
+        Chain9<T> ch;
+        iiwa_chain9(q9, ch);
+        ATACOM_MARK("DYN_rnea"); phase();
+        rnea9<T, true>(ch, dq9, zero9, h9);
+        ATACOM_MARK("DYN_crba"); phase();
+        crba<T, 6, 9>(ch, Ml, Mss);
+        ATACOM_MARK("DYN_servo"); phase();
 #pragma unroll
-    for (int d = 0; d < 3; ++d) { z6[d] = ch.a[5][d]; z7[d] = ch.a[6][d]; y7[d] = ch.a[7][d]; }
-#endif
+        for (int d = 0; d < 3; ++d) { z6[d] = ch.a[5][d]; z7[d] = ch.a[6][d]; y7[d] = ch.a[7][d]; }
+    }
     const T tgt[3] = {joint7_target(z6, z7, st.qx[0]), universal_target(z7, y7), T(0)};
     constexpr T vmax[3] = {T(1.5 * 2.356194490192345), T(1.5 * 3.1415926), T(1.5 * 3.1415926)};     // urdf:297,384,397
     constexpr T effort_s[3] = {T(40), T(10), T(10)};                                                // urdf:297,384,400
@@ -402,9 +410,9 @@ __device__ __forceinline__ void rigid_body_substep(const Params<T>& P, EnvState<
         for (int s2 = 0; s2 < 3; ++s2) r = num<T>::fma(-Ml[6 + s2][i], dds[s2], r);
         rhs[i] = r;
     }
-    ATACOM_MARK("DYN_solve"); ATACOM_PHASE();
+    ATACOM_MARK("DYN_solve"); phase();
     chol_solve<T, 6, 9>(Ml, rhs);
-    ATACOM_MARK("DYN_end"); ATACOM_PHASE();
+    ATACOM_MARK("DYN_end"); phase();
 #pragma unroll
     for (int i = 0; i < 6; ++i) ddq[i] = rhs[i];
 #pragma unroll
@@ -608,8 +616,14 @@ __device__ __forceinline__ void iiwa_prepare_group(const Params<T>& P, const T (
 // CHART = 1: the opt-in canonical chart (atacom_chart.h) instead of the reference's LAPACK-basis + rref(tol) chart; with
 // LANES > 1 its square-root recursion is distributed over the lanes of the group (one vector per lane with 8 lanes).
 // THREADS: threads per workgroup of the calling kernel (sizes the LDS slice the rigid-body mode parks its solver state in)
+// PARKDYN (rigid-body mode, lane groups): park the held solver state in LDS across the dynamics.  Since the dynamics run in link
+// coordinates (round 5) the step and rollout kernels fit without it and are 6 % faster (42.7 against 45.6 us per step, quad,
+// 8192 environments).  The policy kernel keeps it: built without, its in-kernel network sees a wrong observation for three
+// of every four environments of a wavefront from the second step on (found by test_policy_rollout_in_rigid_body_mode; the
+// same source with world-coordinate dynamics, or with the parking, is exact -- a register-level effect in the one kernel that
+// holds four GEMM blocks, the solver state and the dynamics at once; cause not isolated, profiles/r05_dyn_mlp_park.md).
 template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, bool HOIST_G0 = true, int CHART = 0,
-          int THREADS = BLOCK<LANES>, typename Ref>
+          int THREADS = BLOCK<LANES>, bool PARKDYN = false, typename Ref>
 __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st, const T (&act)[E::NK],
                                          StepOut<T>& out, const int lq, const Ref& ref) {
     using L = Planes<E>;
@@ -899,13 +913,16 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                 // and the mass-matrix rows need ~300 registers of their own, and next to the held state the kernels spilled
                 // to scratch (32 - 200 bytes per lane through global memory, per sub-step).  21 ds_write_b128 + 21
                 // ds_read_b128 per sub-step instead; every lane owns its slice, no barrier.
-                constexpr bool PARK = std::is_same<T, float>::value && !CANON && E::MODE == 0 && ATACOM_DYN_PARK &&
-                                      LANES > 1;       // (one environment per lane: measured SLOWER with the parking, 73.9 ->
+#ifndef ATACOM_DYN_PARK_LANE
+#define ATACOM_DYN_PARK_LANE 0      // tuning: park in the one-environment-per-lane single-step kernel as well
+#endif
+                constexpr bool PARK = std::is_same<T, float>::value && !CANON && E::MODE == 0 && (ATACOM_DYN_PARK || PARKDYN) &&
+                                      (LANES > 1 || (ATACOM_DYN_PARK_LANE && THREADS == 64));       // (one environment per lane: measured SLOWER with the parking, 73.9 ->
                                                        // 90.7 us per step at 8192 environments -- those kernels still spill and pay
                                                        // the LDS traffic on top; and the lane-mapped policy kernel's own 100 KB of
                                                        // LDS would leave no room)
                 if constexpr (PARK) {
-                    constexpr int NV = NC * SQ + NC + NC + 2 * NQ, NG4 = (NV + 3) / 4;
+                    constexpr int NV = (LANES > 1 ? NC * SQ + NC : NC * NQ) + NC + 2 * NQ, NG4 = (NV + 3) / 4;
                     __shared__ float4 parked[NG4 * THREADS];
                     T pk[NG4 * 4];
                     int k = 0;
@@ -913,9 +930,14 @@ __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st,
                         k = 0;
 #pragma unroll
                         for (int r = 0; r < NC; ++r) {
+                            if constexpr (LANES > 1) {
 #pragma unroll
-                            for (int sl = 0; sl < SQ; ++sl) f(Aq[r][sl]);
-                            f(A[r][0]);
+                                for (int sl = 0; sl < SQ; ++sl) f(Aq[r][sl]);
+                                f(A[r][0]);
+                            } else {
+#pragma unroll
+                                for (int c = 0; c < NQ; ++c) f(A[r][c]);
+                            }
                         }
 #pragma unroll
                         for (int r = 0; r < NC; ++r) f(yb[r]);
@@ -1386,7 +1408,7 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
         // (one environment per lane with the network's four GEMM blocks live is the one kernel at the edge of the register
         // file: with the G(0) hoist its spills move INTO the sub-step loop -- 59.6 -> 79.5 us per step, measured -- so it
         // keeps the un-hoisted solver)
-        env_step<T, E, LANES, HOLD, DYN, (LANES > 1), CHART, THREADS>(P, st, act, out, lq, ref);
+        env_step<T, E, LANES, HOLD, DYN, (LANES > 1), CHART, THREADS, /*PARKDYN*/ DYN>(P, st, act, out, lq, ref);
         if (lq == 0 && valid) {
             if (rec) {
                 write_obs<T, E>(P, st, rrow + R::NOBS, ref);
