@@ -103,20 +103,27 @@ def algorithmic_flops_canonical(env):
 
 
 def algorithmic_flops_dyn():
-    """FLOPs the rigid-body mode (row N4, dynamics_mode 1 / 2) adds to one iiwa env-step: per physics sub-step the nine-body
-    chain, one Newton-Euler pass, the 9 x 6 mass-matrix rows, servo set-points, torque, Cholesky solve -- counted loop by
-    loop from rl_on_manifold_amd/csrc/atacom_dynamics.h and atacom_kernels.h:rigid_body_substep (FMA = 2, a cross product
-    = 9, a symmetric 3 x 3 product = 15, sincos / acos = 20; selects, compares and moves not counted)."""
-    cross, sym, trig = 9, 15, 20
-    body = 18 + 45 + 30                                               # centre of mass, R I, (R I) R^T
-    chain = 7 * (6 + 18 + trig + body) + 6 + 2 * (trig + 18 + body)   # seven arm joints, the universal joint
-    fwd = 3 + 3 * cross + 6 + 3 + cross + 6 + 3 + 3 * cross + 9 + 2 * sym + cross + 3       # per body, base to tip
-    bwd = 3 + cross + 3 + 3 + 3 + cross + 6 + 5                                              # per joint, tip to base
-    rnea = 9 * (fwd + bwd)
-    crba = 6 * cross + 9 * 36 + 9 * (cross + 6 + sym + cross + 3) + 3 * cross + 3 * 13 + 39 * 11   # composites, rows, entries
+    """FLOPs the rigid-body mode (row N4, dynamics_mode 1 / 2) adds to one iiwa env-step: per physics sub-step the nine sines /
+    cosines, one Newton-Euler pass, the 9 x 6 mass-matrix rows, servo set-points, torque, Cholesky solve -- counted operation
+    by operation from rl_on_manifold_amd/csrc/atacom_dynamics_link.h (the LINK-COORDINATE recursions the kernels run since
+    round 5; the world-coordinate form of rounds 2 - 4 counted 4545 per sub-step) and atacom_kernels.h:rigid_body_substep
+    (FMA = 2, a general cross product = 9, a symmetric 3 x 3 product = 15, sincos / acos = 20, moving a vector across a joint
+    = 6, a symmetric tensor = 23; selects, compares, sign flips and moves not counted)."""
+    cross, sym, trig, xvec, xsym = 9, 15, 20, 6, 23
+    trig9 = 9 * trig
+    # Newton-Euler, base to tip: origin acceleration (offset along one axis: 15), three vectors into the child frame, the joint's
+    # own terms (6), centre-of-mass acceleration (3 cross products), F = m a (9), N = I al + w x (I w) (2 sym + cross + 3)
+    fwd = 8 * 15 + 9 * (3 * xvec + 6 + 3 * cross + 9 + 2 * sym + cross + 3)
+    # tip to base: c x F, accumulate (9), two vectors into the parent frame, offset moment (4)
+    bwd = 9 * (cross + 9) + 8 * (2 * xvec + 4)
+    # composites: first moment + tensor into the parent frame, parallel-axis shift along one axis (12), the body's own (10)
+    comp = 8 * (xvec + xsym + 12) + 9 * 10
+    # rows: (p, L) walked down the chain, 6 + 7 + 8 transforms for the servo rows and 0 .. 5 for the controlled joints
+    rows = (15 + 21) * (2 * xvec + 4)
+    axes = 7 * 18                                                         # orientation chain for the servo set-points
     servo = (2 * cross + 12 + 3 + 5 + trig + 6) + (trig + cross + 12) + 3 * 8
     solve = 6 * (2 * 9) + 6 * (2 * 5) + (6 ** 3 // 3 + 2 * 36 + 30) + 12                    # torque, right-hand side, Cholesky
-    return SHAPES['iiwa'][4] * (chain + rnea + crba + servo + solve)
+    return SHAPES['iiwa'][4] * (trig9 + fwd + bwd + comp + rows + axes + servo + solve)
 
 
 # ------------------------------------------------------------------------------------------ rank spawning
