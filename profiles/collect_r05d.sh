@@ -14,7 +14,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_planar -o s -- 
     python bench.py --env planar --steps 300 --warmup 30 --min-time 0.3 --no-cpu-baseline --no-secondary > $O/bench_planar_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_circle -o s -- \
     python bench.py --env circle --batch 4096 --steps 300 --warmup 30 --min-time 0.3 --no-cpu-baseline --no-secondary > $O/bench_circle_under_rocprof.log 2>&1
-for W in "0 8192 iiwa reference kinematic" "0 8192 planar reference kinematic" "0 4096 circle reference kinematic"; do
+MB_DYN=rigid_body_ff MB_WARM=60 MB_LANES=4 MB_BATCHES=8192 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dyn -o s -- \
+    python tests/gpu_microbench.py iiwa > $O/dyn_under_rocprof.log 2>&1
+for W in "0 8192 iiwa reference kinematic" "0 8192 planar reference kinematic" "0 4096 circle reference kinematic" "0 8192 iiwa reference rigid_body_ff"; do
   T=$(echo $W | tr ' ' '_')
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$T -o c -- python tests/gpu_pmc_target.py $W > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$T -o c -- python tests/gpu_pmc_target.py $W > /dev/null 2>&1

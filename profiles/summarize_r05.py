@@ -15,9 +15,9 @@ import summarize_r04 as s4                                   # noqa: E402  (one(
 TAG = sys.argv[1] if len(sys.argv) > 1 else 'r05d'
 SRC = os.path.join(os.path.dirname(HERE), 'gpurun_out', 'prof_' + TAG)
 s4.SRC = SRC
-ALGO = {'iiwa': 400 * 8192, 'planar': 220 * 8192, 'circle': 60 * 4096}
+ALGO = {'iiwa': 400 * 8192, 'planar': 220 * 8192, 'circle': 60 * 4096, 'iiwa_dyn': 448 * 8192}
 W = {'iiwa': '0_8192_iiwa_reference_kinematic', 'planar': '0_8192_planar_reference_kinematic',
-     'circle': '0_4096_circle_reference_kinematic'}
+     'circle': '0_4096_circle_reference_kinematic', 'iiwa_dyn': '0_8192_iiwa_reference_rigid_body_ff'}
 
 
 def main():
@@ -26,12 +26,12 @@ def main():
            '| file | step kernel | calls | average us |', '|---|---|---|---|']
     import csv
     for tag, dst in (('stats', 'r05_rocprofv3_kernel_stats.csv'), ('stats_planar', 'r05_rocprofv3_kernel_stats_planar.csv'),
-                     ('stats_circle', 'r05_rocprofv3_kernel_stats_circle.csv')):
+                     ('stats_circle', 'r05_rocprofv3_kernel_stats_circle.csv'), ('stats_dyn', 'r05_rocprofv3_kernel_stats_dyn.csv')):
         shutil.copy(s4.one(tag + '/**/*kernel_stats.csv'), os.path.join(HERE, dst))
         for r in [r for r in csv.DictReader(open(os.path.join(HERE, dst))) if 'k_step' in r['Name']][:1]:
             out.append('| %s | `%s` | %s | %.3f |' % (dst, r['Name'].split('(')[0][:70], r['Calls'], float(r['AverageNs']) / 1e3))
     out += ['', '## HBM traffic and SQ counters per launch (separate `--pmc` passes with `--kernel-trace` only, mean of 20 launches)', '',
-            '| | iiwa 8192 | planar 8192 | circle 4096 |', '|---|---|---|---|']
+            '| | iiwa 8192 | planar 8192 | circle 4096 | iiwa 8192 rigid body (ff) |', '|---|---|---|---|---|']
     rows = {}
     for name, w in W.items():
         f = s4.agg(s4.one('pmc_fetch_%s/**/*counter_collection.csv' % w))
@@ -48,7 +48,7 @@ def main():
                   open(os.path.join(HERE, 'traffic_%s.json' % name), 'w'), indent=1)
         rows[name] = (f, wr, sq, raw, cor)
     def row(label, fn):
-        out.append('| %s | ' % label + ' | '.join(fn(*rows[n], n) for n in ('iiwa', 'planar', 'circle')) + ' |')
+        out.append('| %s | ' % label + ' | '.join(fn(*rows[n], n) for n in ('iiwa', 'planar', 'circle', 'iiwa_dyn')) + ' |')
     row('kernel', lambda f, wr, sq, raw, cor, n: '`%s`' % f['_kernel'][:48])
     row('FETCH_SIZE / WRITE_SIZE (KB)', lambda f, wr, sq, raw, cor, n: '%.1f / %.1f' % (f['FETCH_SIZE'], wr['WRITE_SIZE']))
     row('bytes per launch: raw counters', lambda f, wr, sq, raw, cor, n: '%.0f' % raw)

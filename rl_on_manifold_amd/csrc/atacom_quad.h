@@ -456,7 +456,9 @@ __device__ __forceinline__ void bidiag_solve_null_quad_inl(AF&& aget, A0F&& a0ge
     bidiag_forward_solve<T, M>(d, e, [&](int i) { return y2[i / 2][i % 2]; }, z);
     // [nb_0 .. nb_{K-1}, x] as pairs over the vector index; coordinate 0 replicated (nx0), coordinates >= 1 split
     // RELABEL (8 lanes, K + 1 even): the upper half of the group holds vector (q + H) mod 2H in physical slot q (split_sum)
-    constexpr bool RELABEL = ATACOM_P_RELABEL && LN == 8 && (K + 1) % 2 == 0 && K + 1 >= 4 && K + 1 <= 6;
+    // (K + 1 = 6, the iiwa shape, only: with four vectors the split form is 11 instructions with their wait states against the
+    // butterfly's 12 and a longer dependent chain -- the planar T-step kernel measured 8.8 instead of 8.3 us per step)
+    constexpr bool RELABEL = ATACOM_P_RELABEL && LN == 8 && K + 1 == 6;
     constexpr int HV = (K + 1) / 2;
     const bool hf = RELABEL && (lq >= LN / 2);
     V2 nx[S][KP], nx0[KP];
