@@ -17,13 +17,16 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + \
     os.environ.get('ATACOM_HIPCC_FLAGS', '').split()
-UNITS = ['atacom_iiwa.hip', 'atacom_iiwa_f64.hip', 'atacom_noise_iiwa.hip', 'atacom_noise_iiwa_f64.hip', 'atacom_iiwa_dyn.hip',
+UNITS = ['atacom_iiwa.hip', 'atacom_iiwa_group.hip', 'atacom_iiwa_f64.hip', 'atacom_noise_iiwa.hip', 'atacom_noise_iiwa_f64.hip', 'atacom_iiwa_dyn.hip',
          'atacom_iiwa_dyn_f64.hip', 'atacom_iiwa_dyn_chart.hip', 'atacom_chart_iiwa.hip', 'atacom_planar.hip',
          'atacom_noise_planar.hip', 'atacom_chart.hip', 'atacom_circle.hip',
          'atacom_capi.cpp']           # longest first: the pool runs min(cores, units) compilers
-# per-unit extra flags (none at present: -amdgpu-sched-strategy=max-ilp was tried per unit -- planar step kernel -4 %,
-# planar policy-rollout kernel +19 %, iiwa quad kernel +8 % -- and dropped, profiles/r01_lanes_vs_batch.md)
-UNIT_FLAGS = {}
+# per-unit extra flags.  atacom_iiwa_group.hip holds the 4- / 8-lane float32 iiwa kernels alone so that they can take the
+# iterative-ilp scheduler (-1.0 % on the headline step, profiles/r05_ab_sched.log) without the lane kernels of the same source
+# paying for it (+29 % on the lane rollout kernel, r04_ab_sched_iterative_ilp.log; the option also crashes the compiler on
+# float64 instantiations).  (-amdgpu-sched-strategy=max-ilp was tried per unit in round 1 -- planar step kernel -4 %, planar
+# policy-rollout kernel +19 %, iiwa quad kernel +8 % -- and dropped, profiles/r01_lanes_vs_batch.md; round 5: +0.7 % on the headline)
+UNIT_FLAGS = {'atacom_iiwa_group.hip': ['-mllvm', '-amdgpu-sched-strategy=iterative-ilp']}
 
 
 def _sources():
