@@ -216,6 +216,38 @@ def test_noise_moments_against_the_reference_formulas():
     assert np.allclose(seen, want, rtol=1e-12), (seen, want)
 
 
+def test_seed_rekeys_the_device_generator_and_set_state_restarts_the_filter():
+    """`seed()` used to be a no-op, so two experiments calling mdp.seed(s) with different s shared one noise stream:
+    atacom_set_seed re-keys the counter-based generator -- seed(s) on a handle built with another seed == a handle built with s,
+    bit for bit -- and atacom_set_state restarts the obs_delay filter on the injected velocities (a reset does; a stale filter
+    had the controller's dq disagree with the state just set)."""
+    B = 256
+    kw = dict(random_init=True, auto_reset=True, horizon=9, **ALL)
+    acts = torch.rand(12, B, 3, device=DEV) * 2 - 1
+    a = _env('planar', B, 'f32', seed=3, **kw)
+    b = _env('planar', B, 'f32', seed=7, **kw)
+    c = _env('planar', B, 'f32', seed=3, **kw)
+    c.seed(7)                                                     # before the first reset that matters: re-key, then reset
+    outs = []
+    for e in (a, b, c):
+        e.reset()
+        outs.append(e.rollout(acts))
+    assert not torch.equal(outs[0]['obs'], outs[1]['obs'])        # different seeds: different draws
+    # (the constructors' own resets drew episodes 0 / 1 under the old key: only draws keyed by the running episode count, and
+    # that is the episode the reset above started -- under seed 7 in both b and c)
+    for k in outs[1]:
+        assert torch.equal(outs[1][k], outs[2][k]), k
+    e = _env('iiwa', 64, 'f64', obs_delay=True)
+    st = e.get_state()
+    st[:, 6:12] = torch.linspace(-0.2, 0.2, 6, device=DEV, dtype=torch.float64)      # joint velocities
+    st[:, 23 + 3:23 + 6] = torch.tensor([0.1, -0.05, 0.3], device=DEV, dtype=torch.float64)   # puck velocities
+    fv = e.get_filter_state(); fv[:] = 9.0
+    e.set_filter_state(fv)                                        # a stale filter ...
+    e.set_state(st)                                               # ... is restarted by the injected state
+    fv = e.get_filter_state()
+    assert torch.equal(fv[:, :3], st[:, 26:29]) and torch.equal(fv[:, 3:], st[:, 6:12])
+
+
 def test_noise_facade_snapshot_and_refusals():
     """The reference surface: AirHockeyIiwaAtacom(obs_noise=True, obs_delay=True) and the planar twin construct and step
     (envs.py used to raise NotImplementedError); a snapshot carries filter state and episode ids (restore, repeat: the same
