@@ -44,3 +44,17 @@ for comp in range(18):
     d = (net(o2) - want).abs().amax(1)
     print('  component %2d from t-1: matching %d' % (comp, int((d < 2e-4).sum())), end=';')
 print()
+
+# chunk-level hypothesis: some 4-float chunks of the staged observation row are stale (from t - 1)
+import itertools
+best = []
+for mask in range(32):
+    o2 = out['obs'][t].clone()
+    for ch in range(5):
+        if mask >> ch & 1:
+            lo, hi = 4 * ch, min(4 * ch + 4, 18)
+            o2[:, lo:hi] = out['obs'][t - 1][:, lo:hi]
+    d = (net(o2) - want).abs().amax(1)
+    best.append((int((d < 2e-4).sum()), mask))
+best.sort(reverse=True)
+print('stale-chunk hypotheses (matching envs, chunk mask):', best[:6])
