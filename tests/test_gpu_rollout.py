@@ -670,6 +670,29 @@ def test_default_mapping_is_deterministic_across_processes(tmp_path):
     assert (auto.lanes_per_env, auto.rollout_lanes_per_env) == (8, 8)
 
 
+@pytest.mark.parametrize('mode,lanes', [('kinematic', 1), ('kinematic', 2), ('kinematic', 4), ('kinematic', 8),
+                                        ('rigid_body_ff', 1), ('rigid_body_ff', 4)])
+def test_policy_kernel_network_sees_the_observation_it_writes(mode, lanes):
+    """A network that COPIES five of its inputs to its outputs (ReLU kept linear by a hidden bias of +10, output bias -10),
+    run for every input window: the action of step t must be the observation the kernel itself wrote for step t, in every
+    environment of the batch.  Guards the staging of the in-kernel network (observation rows, biases, weights in LDS and
+    registers) against lane- or step-dependent corruption -- round 5 met a build that passed step 0 and was off by exactly one
+    bias for three of every four environments afterwards (profiles/r05_dyn_mlp_park.md)."""
+    from rl_on_manifold_amd import BatchedAtacomEnv, MlpPolicy
+    B, T = 1000, 6
+    for j0 in (0, 5, 10, 13):
+        W1 = torch.zeros(64, 18); W1[:18, :18] = torch.eye(18)
+        W3 = torch.zeros(5, 64)
+        for k in range(5):
+            W3[k, j0 + k] = 1.0
+        pol = MlpPolicy(W1, torch.full((64,), 10.0), torch.eye(64), torch.zeros(64), W3, torch.full((5,), -10.0), std=torch.zeros(5))
+        env = BatchedAtacomEnv('iiwa', B, device=DEV, dynamics_mode=mode, lanes_per_env=lanes, random_init=True, seed=3)
+        env.reset()
+        out = env.rollout_policy(pol, T)
+        d = (out['action'] - out['obs'][:, :, j0:j0 + 5]).abs()
+        assert float(d.max()) < 1e-4, (mode, lanes, j0, torch.nonzero(d.amax(2) > 1e-4)[:8].tolist())
+
+
 def test_graphed_rollout_leaves_no_warmup_residue():
     """GraphedRollout warms up with real steps before the capture: they must not stay in the constraint
     statistics nor shift the device-side random resets -- the first replay equals the rollout kernel of a twin engine that
