@@ -318,7 +318,7 @@ static int check_mlp(const atacom_handle* h, const atacom_mlp* net, const char* 
 extern "C" {
 
 const char* atacom_last_error(void) { return g_err.c_str(); }
-const char* atacom_version(void) { return "atacom_hip 0.4 (gfx950)"; }
+const char* atacom_version(void) { return "atacom_hip 0.5 (gfx950)"; }
 
 int atacom_get_dims(int32_t env_id, atacom_dims* out) {
     const atacom::EnvOps* ops = get_ops(env_id, ATACOM_F32);
