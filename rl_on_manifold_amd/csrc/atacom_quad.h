@@ -723,39 +723,25 @@ __device__ __forceinline__ void rref_apply_quad_inl(T (&nb0)[K], T (&nb)[split_s
     }
 }
 
-// ---- entry points.  float (production): everything inlined into the one straight-line kernel.  double (parity
-// build): the two big pieces are kept as real functions.  Reason: hipcc 7.2 miscompiles the fully inlined
-// k_step<double, Iiwa, 4, false> (512 VGPRs + 0.9 KB scratch: garbage in mu at -O3 and -O1 alike, while the same source
-// is exact as float, as double with HOLD = true, and as double with either piece outlined) -- found by
-// tests/test_gpu_parity.py::test_refresh_and_exact_bias_variants_against_oracle.  Outlining keeps the double kernels
-// far from the register ceiling; their speed is irrelevant.
-template <typename T, int M, int N, int LN, bool PRE0, typename AF, typename A0F, typename YF>
-__device__ __attribute__((noinline)) void bidiag_solve_null_quad_out(AF& aget, A0F& a0get, YF& yget, T& x0,
-                                                                     T (&x)[split_slots(N, LN)], T (&nb0)[N - M],
-                                                                     T (&nb)[split_slots(N, LN)][N - M], const int lq,
-                                                                     const T pre_d0, const T pre_tau0) {
-    bidiag_solve_null_quad_inl<T, M, N, LN, PRE0>(aget, a0get, yget, x0, x, nb0, nb, lq, pre_d0, pre_tau0);
-}
+// ---- entry points: everything inlined into the one straight-line kernel, float and double alike.
+// History: rounds 1 - 5 kept the two big pieces as real (noinline) functions in the double build, after hipcc 7.2 had been seen
+// to miscompile the fully inlined k_step<double, Iiwa, 4, false> in round 1 (found by tests/test_gpu_parity.py::
+// test_refresh_and_exact_bias_variants_against_oracle).  The calls cost the double kernels their registers: arrays handed over
+// by reference live in scratch (1.6 - 2.6 KB per lane; 183 of 331 double kernels), the callee-save convention pins 512
+// registers -- 112.7 us per step at 8192 iiwa environments on 8 lanes.  Round 6 inlined them again: the same test and the
+// other 124 float64 tests pass at 1e-8 on every mapping, the 8-lane step kernel holds 256 + 228 registers and no scratch and
+// runs 50.2 us (profiles/r06_f64_inline.md).
 template <typename T, int M, int N, int LN = 4, bool PRE0 = false, typename AF, typename A0F, typename YF>
 __device__ __forceinline__ void bidiag_solve_null_quad(AF&& aget, A0F&& a0get, YF&& yget, T& x0,
                                                        T (&x)[split_slots(N, LN)], T (&nb0)[N - M],
                                                        T (&nb)[split_slots(N, LN)][N - M], const int lq,
                                                        const T pre_d0 = T(0), const T pre_tau0 = T(0)) {
-    if constexpr (std::is_same<T, double>::value)
-        bidiag_solve_null_quad_out<T, M, N, LN, PRE0>(aget, a0get, yget, x0, x, nb0, nb, lq, pre_d0, pre_tau0);
-    else bidiag_solve_null_quad_inl<T, M, N, LN, PRE0>(aget, a0get, yget, x0, x, nb0, nb, lq, pre_d0, pre_tau0);
-}
-template <typename T, int N, int K, int LN>
-__device__ __attribute__((noinline)) void rref_apply_quad_out(T (&nb0)[K], T (&nb)[split_slots(N, LN)][K],
-                                                              const T (&alpha)[K], T tol, T& out0,
-                                                              T (&out)[split_slots(N, LN)], const int lq) {
-    rref_apply_quad_inl<T, N, K, LN>(nb0, nb, alpha, tol, out0, out, lq);
+    bidiag_solve_null_quad_inl<T, M, N, LN, PRE0>(aget, a0get, yget, x0, x, nb0, nb, lq, pre_d0, pre_tau0);
 }
 template <typename T, int N, int K, int LN = 4>
 __device__ __forceinline__ void rref_apply_quad(T (&nb0)[K], T (&nb)[split_slots(N, LN)][K], const T (&alpha)[K], T tol,
                                                 T& out0, T (&out)[split_slots(N, LN)], const int lq) {
-    if constexpr (std::is_same<T, double>::value) rref_apply_quad_out<T, N, K, LN>(nb0, nb, alpha, tol, out0, out, lq);
-    else rref_apply_quad_inl<T, N, K, LN>(nb0, nb, alpha, tol, out0, out, lq);
+    rref_apply_quad_inl<T, N, K, LN>(nb0, nb, alpha, tol, out0, out, lq);
 }
 
 }  // namespace atacom
