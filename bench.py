@@ -72,8 +72,43 @@ def algorithmic_flops(env):
     f += 2 * N * K + N                                                # Nc @ alpha - x
     f += 6 * M + 14 * nq                                              # rhs assembly, slack, truncation, integration
     per_sub = f
-    fk = {'circle': 20, 'planar': 150, 'iiwa': 1500}[env]             # constraint terms + post-step kinematics
-    return sub * per_sub + 2 * fk + 4 * M * nq
+    return sub * per_sub + sum(once_per_step_flops(env).values())
+
+
+def once_per_step_flops(env):
+    """FLOPs of what an env step does ONCE (not per physics sub-step, with the reference's zero-order hold of q, dq): counted
+    operation by operation from rl_on_manifold_amd/csrc/atacom_envs.h (constraint_terms, constraint_fun, bias_mode 0) and
+    atacom_kernels.h (env_step: assembly, puck sub-steps, reward, truncation bounds); FMA = 2, add / mul / div / sqrt / rcp = 1,
+    sincos / exp = 20 (the convention of algorithmic_flops_dyn); negations, selects, compares, abs / min / max not counted.
+    (Rounds 1 - 5 carried an ESTIMATE here -- 2 x 1500 for iiwa: 1.8 kFLOP, 3.4 % of the step, too many.)"""
+    M, N, K, nq, sub = SHAPES[env]
+    nnz = sum(ROW_NNZ[env])
+    sincos, exp = 20, 20
+    assembly = 2 * nnz + 2 * nnz + 6 * M                     # J dq, K J, (psi, c0, yb) per row
+    trunc = 4 * nq                                            # acc_truncation bounds (atacom.py:117-121)
+    action = 3 * K                                            # clip * alpha_max, |alpha|^2
+    # puck: per physics sub-step mallet interpolation 5, integration 6, distance 6 + rcp, normal 2, relative velocity 5,
+    # impulse 2 + 4, push-out 4, rims 8, hit latch 3 = 46;  reward / termination: 3 + distances 8 + 2 rcp + cosine 5 + exp + 6
+    puck = 46 * sub + 3 + 8 + 2 + 5 + exp + 6
+    if env == 'circle':
+        terms = 4 + 1 + 2 + 5                                 # f, g, J_f, b_f  (circle_atacom.py:47-70)
+        post = 0
+        other = 5 + 2 * 8 + 5 + exp                           # pre-step log, base integration (circle_base.py:59-63), reward
+        return {'constraint_terms': terms, 'assembly': assembly, 'post_step_kinematics': post, 'truncation_bounds': trunc,
+                'action': action, 'base_env': other}
+    if env == 'planar':
+        fk = 3 * sincos + 3 + 6                               # planar_fk: cumulative angles, link vectors
+        terms = fk + 6 + 3 + 6 + 12 + 3 + 2 + 9 + 3 + 6       # tip, table rows, J sums, v = J dq, w, w x v, limits, 2 q, 2 dq^2
+        post = fk + 6 + 3 + 9
+    else:
+        chain = 6 * (6 + 9 + 9) + 12                          # iiwa_chain: origin, two rotated axes per joint; link_7 + tip
+        fk = 6 * sincos + chain
+        jac = 12 * (6 + 6 + 2)                                # jac_col: z x (p - o), tip / link_7 (6 columns) / link_4 (2)
+        bias = 2 * (36 + 36 + 9) + (24 + 24 + 9)              # frame_bias mode 0: w, v = J dq, w x v (6-, 6-, 4-joint frames)
+        terms = fk + jac + bias + 8 + 18 + 6 + 12             # table / height rows, limits, 2 q, 2 dq^2
+        post = fk + 8 + 18
+    return {'constraint_terms': terms, 'assembly': assembly, 'post_step_kinematics': post, 'truncation_bounds': trunc,
+            'action': action, 'puck_reward_termination': puck}
 
 
 # structural non-zeros per row of K J (rl_on_manifold_amd/csrc/atacom_envs.h: jac_zero), equality row first
@@ -98,8 +133,7 @@ def algorithmic_flops_canonical(env):
     f += 3 * n1 * n1 + 2 * sum(g_rows) + 3 * len(g_rows)              # slack stage (B)
     f += 4 * nq + 2 * sum(g_rows) + 3 * len(g_rows)                   # equality row once more, slack velocities
     per_sub = 2 * f + 6 * M + 14 * nq
-    fk = {'circle': 20, 'planar': 150, 'iiwa': 1500}[env]
-    return sub * per_sub + 2 * fk + 4 * M * nq
+    return sub * per_sub + sum(once_per_step_flops(env).values())
 
 
 def algorithmic_flops_dyn():
@@ -490,8 +524,12 @@ def main():
                                '(%.1f %% of draws rejected); puck uniform in the hit range' % (100 * rejected)
                                if args.env != 'circle' else 'half fixed reset point, half random valid states',
                        'parallelism': 'env-shard x%d, no data-path collective' % world},
+            # spread of the K-step blocks next to the median `ms_per_step` is computed from (one block in
+            # ~3000 took 70 x the median -- a host hiccup, visible here instead of hidden by the median)
+            'block_ms_p99': float(np.percentile(secs, 99)) * 1e3, 'block_ms_max': max(secs) * 1e3,
             'timing': {'blocks': len(secs), 'block_steps': K, 'block_ms_median': elapsed * 1e3,
-                       'block_ms_min': min(secs) * 1e3, 'block_ms_max': max(secs) * 1e3,
+                       'block_ms_min': min(secs) * 1e3, 'block_ms_p99': float(np.percentile(secs, 99)) * 1e3,
+                       'block_ms_max': max(secs) * 1e3,
                        'timed_seconds_total': float(sum(secs)), 'statistic': 'median over blocks of (max over ranks)'},
             'max_abs_c': c_max, 'c_avg': c_avg, 'c_dq_max': c_dq_max,
             'collection': collection,
@@ -502,6 +540,7 @@ def main():
     if world == 1 and rank == 0:
         if not args.no_secondary and args.env == 'iiwa' and args.batch == 8192:
             result['secondary'] = secondary_records(dev, gen, K, W, sync_all, max_over_ranks)
+            result['saturation'] = saturation_records(dev, gen, K, W, sync_all, max_over_ranks)
         if not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.env, args.cpu_seconds, dev, init, k)
     if rank == 0:
@@ -516,7 +555,7 @@ def main():
 
 def measured_traffic(name, chart='reference', dyn=False, lanes=0):
     """HBM bytes per launch of the step kernel at the BASELINE batch, from the committed counter passes (rocprofv3 --pmc
-    FETCH_SIZE and --pmc WRITE_SIZE in separate runs of tests/gpu_pmc_target.py, summarised into profiles/traffic_*.json) --
+    FETCH_SIZE and --pmc WRITE_SIZE in separate runs of profiles/tools/gpu_pmc_target.py, summarised into profiles/traffic_*.json) --
     NOT measured inside this run: bench.py cannot host the profiler, the line says where the figure comes from
     (`traffic_source`).  Corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts a 16 B / lane streaming
     read at half its bytes (128-byte requests tallied at 64), so the fetch side is doubled; WRITE_SIZE is taken as counted.
@@ -572,6 +611,83 @@ def rccl_selfgather(env, rec, dev, reps=5):
         return {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
 
 
+def tstep_record(name, B, T, dev, gen, dtype=None, reps=4, init=True):
+    """The T-step kernel (atacom_rollout: state in registers, one launch for T steps of B environments) timed with HIP events
+    on the launch stream, with BOTH rooflines.  HBM view: the bytes the launch must move -- actions in, (obs, next_obs,
+    reward, absorbing, last) out, per (step, environment); the state itself moves once per launch (counted).  Returns a
+    record dict.  `init`: feasible initial states of the bench protocol (planar / iiwa)."""
+    import torch
+    from rl_on_manifold_amd import BatchedAtacomEnv
+    dtype = dtype or torch.float32
+    if init and name != 'circle':
+        env, _, _ = make_env(name, B, dev, gen, dtype=dtype)
+    elif name == 'circle':
+        env, _, _ = make_env(name, B, dev, gen, dtype=dtype)
+    else:
+        env = BatchedAtacomEnv(name, B, device=dev, dtype=dtype, auto_reset=True)
+    k = env.dims['null']
+    acts = (torch.rand((T, B, k), device=dev, generator=gen) * 2 - 1).to(dtype)
+    out = env.rollout(acts)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        env.rollout(acts, out=out)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    c_avg, c_max, c_dq = env.get_constraints_logs()
+    esz = acts.element_size()
+    io_bytes = acts.numel() * esz + sum(v.numel() * v.element_size() for v in out.values() if torch.is_tensor(v))
+    state_bytes = 2 * B * esz * {'circle': 5, 'planar': 21, 'iiwa': 34}[name]         # hot state read + written once per launch
+    nbytes = io_bytes + state_bytes
+    flops = algorithmic_flops(name) * B * T
+    f64 = dtype == torch.float64
+    peak = VALU_F64_PEAK_TF if f64 else VALU_F32_PEAK_TF
+    tf, gbs = flops / (ms * 1e-3) / 1e12, nbytes / (ms * 1e-3) / 1e9
+    valu = {'bound': 'valu_f64' if f64 else 'valu_f32', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
+            'algorithmic_flops_per_launch': flops}
+    hbm = {'bound': 'hbm', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+           'algorithmic_bytes_per_launch': nbytes, 'bytes_per_env_step': nbytes / (B * T)}
+    binding = hbm if hbm['frac'] > valu['frac'] else valu
+    rec = {'workload': '%s, batch %d, T-step kernel (atacom_rollout, %d steps per launch)' % (WORKLOAD[name], B, T),
+           'path': 'atacom_rollout (1 launch / %d steps) via C ABI' % T, 'value': B * T / (ms * 1e-3), 'unit': 'env-steps/s',
+           'us_per_step': ms / T * 1e3, 'launch_ms': ms, 'launches_timed': reps, 'lanes_per_env': env.rollout_lanes_per_env,
+           'max_abs_c': c_max, 'c_avg': c_avg, 'c_dq_max': c_dq, 'roofline': dict(binding, kernel_ms=ms),
+           'roofline_other': dict(valu if binding is hbm else hbm, kernel_ms=ms)}
+    env.close()
+    del out, acts
+    return rec
+
+
+def saturation_records(dev, gen, K, W, sync_all, max_over_ranks):
+    """the headline batch (8192 environments) is ONE wavefront per SIMD -- its roofline fraction is the
+    occupancy of the configuration, not the quality of the kernels.  These records put the same kernels at batches that fill
+    the machine into the driver-run line: config 5's global batch (65536 iiwa environments) on ONE GPU through atacom_step and
+    through the T-step kernel, and the planar / circle T-step kernels at their saturation batches (circle is the one
+    HBM-bound configuration: its binding roof is `hbm`)."""
+    import numpy as np
+    import torch
+    out = []
+    B = 65536
+    env, _, rej = make_env('iiwa', B, dev, gen)
+    acts = torch.rand((16, B, 5), device=dev, generator=gen) * 2 - 1
+    secs, kern_ms = time_steps(env, acts, K, min(W, 5), 0.4, sync_all, max_over_ranks)
+    el = float(np.median(secs))
+    c_avg, c_max, c_dq = env.get_constraints_logs()
+    roof, roof_hbm = roofline_objects('iiwa', B, kern_ms, None)
+    out.append({'workload': 'IiwaAirHockey env 7H, batch 65536 on ONE GPU (config 5\'s global batch), single steps',
+                'path': 'atacom_step (1 launch / step) via C ABI', 'value': B * K / el, 'unit': 'env-steps/s',
+                'ms_per_step': el / K * 1e3, 'blocks': len(secs), 'lanes_per_env': env.lanes_per_env,
+                'max_abs_c': c_max, 'c_avg': c_avg, 'c_dq_max': c_dq, 'roofline': roof, 'roofline_hbm': roof_hbm})
+    env.close()
+    del acts
+    out.append(tstep_record('iiwa', 65536, 40, dev, gen))
+    out.append(tstep_record('planar', 262144, 40, dev, gen))
+    out.append(tstep_record('circle', 1048576, 60, dev, gen))
+    return out
+
+
 def secondary_records(dev, gen, K, W, sync_all, max_over_ranks):
     """BASELINE configs 2 and 3 (circle A batch 4096, planar H batch 8192): same timing protocol, shorter."""
     import numpy as np
@@ -599,7 +715,11 @@ def secondary_records(dev, gen, K, W, sync_all, max_over_ranks):
                'c_dq_max': c_dq, 'rollout_kernel_env_steps_per_s': roll,
                'hip_graph_20_steps_us_per_step': g_us, 'roofline': roof,
                'roofline_hbm': roof_hbm}
+        rec['path'] = 'atacom_step (1 launch / step) via C ABI; rollout_kernel_env_steps_per_s: atacom_rollout_packed, 120 steps / launch'
         if name == 'circle':
+            # the T-step kernel is the real path for this task (a single circle step is launch-bound): the same batch through
+            # atacom_rollout, HIP-event timed, with its own rooflines
+            rec['tstep'] = tstep_record('circle', B, 500, dev, gen)
             # this configuration is bound by the host's launch path, not by the kernel: the fraction above divides by the time
             # between launches; beside it the kernel-only view, from the committed rocprofv3 kernel statistics of this workload
             k_us = committed_kernel_us('r04_rocprofv3_kernel_stats_circle.csv', 'k_step<float, atacom::Circle') or \

@@ -70,7 +70,14 @@ typedef struct atacom_config {
                               reports them.  ATACOM_CALIBRATE=1 (or =verbose) in the environment opts in to timing
                               8 lanes against 4 for atacom_step of iiwa at 4096 < batch <= 8192 once per process,
                               about 20 ms -- the bits then depend on the box).
-                              Results are the same algorithm in every mapping (summation order differs). */
+                              Results are the same algorithm in every mapping (summation order differs).
+                              Not every mapping exists for every handle; a request runs on the widest instantiated mapping
+                              that is not wider, and atacom_get_lanes reports it: the circle family runs one environment per
+                              lane; float64 handles 1, 4 and (iiwa) 8 lanes -- policy: iiwa 8 up to 8192 envs, 4 up to
+                              16384, else 1; planar 4 up to 16384, else 1; the rigid-body kernels 1 and 4; the planar T-step
+                              kernels take 8 lanes up to 8192 envs where single steps stay on 4; the policy kernel
+                              (atacom_rollout_mlp) follows the T-step mapping where it has that form (float64: 4 or 1) --
+                              atacom_get_policy_lanes. */
     double dt;           /* time_step */
     double rref_tol;     /* 0.05, atacom.py:128 */
     double action_penalty; /* env_hitting.py:10,68 */
@@ -232,16 +239,27 @@ int atacom_rollout_packed(atacom_handle* h, int32_t n_steps, const void* d_actio
 int atacom_get_stats(atacom_handle* h, double out[3], int32_t clear, void* stream);
 
 /* env.seed(seed) (atacom.py:90-91 -> the base env's seed): re-keys the counter-based generator behind the device-side draws
- * (random_init, obs_noise, env_noise: hash(seed, env, episode, step, draw)) from the next launch on.  Host-side only, no
- * device work; launches already captured in a HIP graph keep the seed they were captured with. */
+ * (random_init, obs_noise, env_noise: hash(seed, env, episode, step, draw)) from the next launch on.  The key is stored as
+ * seed & 0x7fffffff (atacom_create stores cfg.seed the same way).  No kernel launch; one synchronous 64-byte host-to-device
+ * copy keeps the snapshot header current (the key travels with atacom_snapshot_save).  Launches already captured in a HIP
+ * graph keep the seed they were captured with. */
 int atacom_set_seed(atacom_handle* h, int32_t seed);
 
-/* The kernel mappings this handle runs: lanes per environment (1, 2, 4 or 8) of atacom_step and of the T-step kernels
- * (atacom_rollout / _mlp / _packed) -- cfg.lanes_per_env, or what the library chose for lanes_per_env = 0 (the two may
- * differ: the persistent state does not depend on the mapping).  Either output pointer may be NULL. */
+/* The kernel mappings this handle REALLY runs: lanes per environment (1, 2, 4 or 8) of atacom_step and of the T-step kernels
+ * (atacom_rollout / _packed with actions) -- cfg.lanes_per_env, or what the library chose for lanes_per_env = 0, narrowed to
+ * the mappings instantiated for the handle's kernel variant (see lanes_per_env above; the two may differ: the persistent
+ * state does not depend on the mapping).  Either output pointer may be NULL.
+ * atacom_get_policy_lanes: the same for the policy kernel (atacom_rollout_mlp, atacom_rollout_packed with a network), which
+ * has fewer forms (float64: quad and lane; float32 8 lanes: the matrix-core form). */
 int atacom_get_lanes(const atacom_handle* h, int32_t* out_step_lanes, int32_t* out_rollout_lanes);
+int atacom_get_policy_lanes(const atacom_handle* h, int32_t* out_policy_lanes);
 
-/* Parity injection / checkpointing: d_state [batch, state_dim]. */
+/* Parity injection: d_state [batch, state_dim] = [q, dq, s, puck(6), has_hit, r_hit, vel_hit_x, t].  NOT a checkpoint (use
+ * atacom_snapshot_*): the stored initial states, statistics, episode counters and servo joints are not part of it, and on a
+ * handle with cfg.obs_delay atacom_set_state RESTARTS the low-pass behind the observation's velocities on the injected state
+ * (as a reset does: a stale filter would have the controller's dq disagree with the state just set) -- so get_state followed
+ * by set_state does not preserve the filter.  To inject a particular filter state call atacom_set_filter_state AFTER
+ * atacom_set_state (that order only). */
 int atacom_get_state(atacom_handle* h, void* d_state, void* stream);
 int atacom_set_state(atacom_handle* h, const void* d_state, void* stream);
 
@@ -254,8 +272,12 @@ int atacom_set_state(atacom_handle* h, const void* d_state, void* stream);
  * shape instead of mis-reading it; save is three device-to-device copies on `stream`, no synchronisation.
  * restore(save(x)) followed by the same calls reproduces the run bit for bit (the reference has no counterpart: its envs
  * are Python objects one would pickle).  The header also records the kernel mappings of the writing handle
- * (atacom_get_lanes): a restoring handle created with lanes_per_env = 0 adopts them, so the replay is bit for bit in
- * another process as well; a handle with a named mapping keeps its own (the state does not depend on the mapping). */
+ * (atacom_get_lanes) and its generator key (cfg.seed / atacom_set_seed): a restoring handle adopts the key, and -- if created
+ * with lanes_per_env = 0 -- the mappings, so the replay is bit for bit in another process as well; a handle with a named
+ * mapping keeps its own (the state does not depend on the mapping).  Launches already captured in a HIP graph keep the
+ * mapping and key they were captured with; a RolloutCollector whose handle's mappings changed refuses to collect (rollout.py).
+ * The header carries a format number: an image written by another library version is refused with that message
+ * (ATACOM_E_INVALID), not mis-read. */
 int64_t atacom_snapshot_bytes(const atacom_handle* h);
 int atacom_snapshot_save(atacom_handle* h, void* d_image, void* stream);
 int atacom_snapshot_restore(atacom_handle* h, const void* d_image, void* stream);
@@ -268,7 +290,8 @@ int atacom_set_aux_state(atacom_handle* h, const void* d_aux, void* stream);
 /* obs_delay (cfg.obs_delay = 1; planar / iiwa handles): the low-pass state behind the observation's velocities,
  * d_filter [batch, 3 + dim_q] = [puck vx, vy, yaw rate, joint velocities] as the last observation showed them
  * (obs_prev[3:6] and the robot-velocity slice of env_single.py:114-119).  Every reset re-initialises it to the unfiltered
- * velocities; get / set exist for parity injection next to atacom_set_state, and atacom_snapshot_* carries it. */
+ * velocities, and so does atacom_set_state: call atacom_set_filter_state AFTER it (the other order is overwritten).  get / set
+ * exist for parity injection; atacom_snapshot_* carries the filter. */
 int atacom_get_filter_state(atacom_handle* h, void* d_filter, void* stream);
 int atacom_set_filter_state(atacom_handle* h, const void* d_filter, void* stream);
 
@@ -304,7 +327,7 @@ int atacom_forward_dynamics(int32_t dtype, int32_t n, const void* d_q, const voi
  *     having zeros there. */
 int atacom_canonical_mu(int32_t env_id, int32_t dtype, int32_t n, const void* d_A, const void* d_s, const void* d_y,
                         const void* d_alpha, double tol, void* d_mu, void* stream);
-int atacom_nullspace(int32_t env_id, int32_t dtype, int32_t lanes_per_env /* 1, 2, 4 or 8 */, int32_t n, const void* d_Jc,
+int atacom_nullspace(int32_t env_id, int32_t dtype, int32_t lanes_per_env /* 1, 2, 4 or 8; narrowed like a handle's request */, int32_t n, const void* d_Jc,
                      const void* d_rhs, double tol, void* d_x, void* d_null, void* d_rref, void* stream);
 int atacom_constraint_terms(const atacom_config* cfg, int32_t n, const void* d_q, const void* d_dq, void* d_fun,
                             void* d_J, void* d_b, void* stream);

@@ -9,11 +9,11 @@ cat $O/dyn_parity.log
 for rep in 1 2; do
   for lib in build/ab/libatacom_r05relabel.so rl_on_manifold_amd/libatacom_hip.so; do
     for mode in rigid_body rigid_body_ff; do
-      ATACOM_LIB=$lib MB_DYN=$mode MB_WARM=60 MB_ROLLOUT=1 MB_LANES=4,1 MB_BATCHES=8192 python tests/gpu_microbench.py iiwa 2>&1 | grep -v "amdgpu.ids\|Warning\|BatchedAtacomEnv("
+      ATACOM_LIB=$lib MB_DYN=$mode MB_WARM=60 MB_ROLLOUT=1 MB_LANES=4,1 MB_BATCHES=8192 python profiles/tools/gpu_microbench.py iiwa 2>&1 | grep -v "amdgpu.ids\|Warning\|BatchedAtacomEnv("
     done
   done
 done > $O/ab_dyn.log
 cat $O/ab_dyn.log
-ATACOM_LIB=rl_on_manifold_amd/libatacom_hip.so MB_DYN=rigid_body_ff MB_WARM=60 MB_ROLLOUT=1 MB_LANES=1 MB_BATCHES=65536 python tests/gpu_microbench.py iiwa 2>&1 | grep -v "amdgpu.ids" >> $O/ab_dyn.log
-ATACOM_LIB=build/ab/libatacom_r05relabel.so MB_DYN=rigid_body_ff MB_WARM=60 MB_ROLLOUT=1 MB_LANES=1 MB_BATCHES=65536 python tests/gpu_microbench.py iiwa 2>&1 | grep -v "amdgpu.ids" >> $O/ab_dyn.log
+ATACOM_LIB=rl_on_manifold_amd/libatacom_hip.so MB_DYN=rigid_body_ff MB_WARM=60 MB_ROLLOUT=1 MB_LANES=1 MB_BATCHES=65536 python profiles/tools/gpu_microbench.py iiwa 2>&1 | grep -v "amdgpu.ids" >> $O/ab_dyn.log
+ATACOM_LIB=build/ab/libatacom_r05relabel.so MB_DYN=rigid_body_ff MB_WARM=60 MB_ROLLOUT=1 MB_LANES=1 MB_BATCHES=65536 python profiles/tools/gpu_microbench.py iiwa 2>&1 | grep -v "amdgpu.ids" >> $O/ab_dyn.log
 tail -4 $O/ab_dyn.log

@@ -9,4 +9,4 @@ for rep in 1 2 3; do for v in r05final hip; do
 done; done > $O/ab_gearly.log
 sort -s -k1,1 $O/ab_gearly.log
 for v in r05final hip; do lib=build/ab/libatacom_$v.so; [ $v = hip ] && lib=rl_on_manifold_amd/libatacom_hip.so
-  ATACOM_LIB=$lib MB_WARM=30 MB_ROLLOUT=1 MB_LANES=4,8 MB_BATCHES=8192 python tests/gpu_microbench.py iiwa planar 2>&1 | grep -v amdgpu.ids; done | tee $O/ab_gearly_microbench.log
+  ATACOM_LIB=$lib MB_WARM=30 MB_ROLLOUT=1 MB_LANES=4,8 MB_BATCHES=8192 python profiles/tools/gpu_microbench.py iiwa planar 2>&1 | grep -v amdgpu.ids; done | tee $O/ab_gearly_microbench.log

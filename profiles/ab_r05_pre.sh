@@ -5,7 +5,7 @@ O=gpurun_out/prof_r05b
 rm -rf $O; mkdir -p $O
 for rep in 1 2 3; do
   for lib in build/ab/libatacom_r05base.so rl_on_manifold_amd/libatacom_hip.so; do
-    ATACOM_LIB=$lib MB_WARM=30 MB_ROLLOUT=1 MB_LANES=8 MB_BATCHES=8192 python tests/gpu_microbench.py iiwa 2>&1 | grep -v amdgpu.ids
+    ATACOM_LIB=$lib MB_WARM=30 MB_ROLLOUT=1 MB_LANES=8 MB_BATCHES=8192 python profiles/tools/gpu_microbench.py iiwa 2>&1 | grep -v amdgpu.ids
   done
 done > $O/ab_pre_microbench.log
 cat $O/ab_pre_microbench.log

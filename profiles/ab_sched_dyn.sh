@@ -4,6 +4,6 @@ cd /root/repo
 O=gpurun_out/ab_sched; mkdir -p $O
 for rep in 1 2; do for v in hip maxilp minreg maxmem maxocc; do
   lib=build/ab/libatacom_dyn_$v.so; [ $v = hip ] && lib=rl_on_manifold_amd/libatacom_hip.so
-  ATACOM_LIB=$PWD/$lib MB_WARM=60 MB_ROLLOUT=1 MB_DYN=rigid_body MB_LANES=4 MB_BATCHES=8192 python tests/gpu_microbench.py iiwa
+  ATACOM_LIB=$PWD/$lib MB_WARM=60 MB_ROLLOUT=1 MB_DYN=rigid_body MB_LANES=4 MB_BATCHES=8192 python profiles/tools/gpu_microbench.py iiwa
 done; done 2>&1 | grep -v amdgpu.ids > $O/ab_sched_dyn.log
 cut -c1-120 $O/ab_sched_dyn.log

@@ -12,18 +12,18 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- \
 # 2. SQ counters, lanes 4 and 8 at 8192 envs (and the clock: GRBM_GUI_ACTIVE)
 for L in 4 8; do
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU \
-      SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_sq_l$L -o c -- python tests/gpu_pmc_target.py $L > /dev/null 2>&1
-  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_grbm_l$L -o c -- python tests/gpu_pmc_target.py $L > /dev/null 2>&1
+      SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_sq_l$L -o c -- python profiles/tools/gpu_pmc_target.py $L > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_grbm_l$L -o c -- python profiles/tools/gpu_pmc_target.py $L > /dev/null 2>&1
 done
 # 3. HBM traffic of the dominant kernel (separate passes)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o c -- python tests/gpu_pmc_target.py 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o c -- python tests/gpu_pmc_target.py 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o c -- python profiles/tools/gpu_pmc_target.py 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o c -- python profiles/tools/gpu_pmc_target.py 0 > /dev/null 2>&1
 # 4. mapping vs batch
-MB_LANES=8,4,2,1 MB_BATCHES=1024,4096,8192,16384,32768,65536 python tests/gpu_microbench.py iiwa planar 2>&1 | grep -v amdgpu.ids > $O/lanes_vs_batch.log
-MB_DYN=rigid_body MB_LANES=4,1 MB_BATCHES=8192,65536 python tests/gpu_microbench.py iiwa 2>&1 | grep -v amdgpu.ids > $O/rigid_body.log
+MB_LANES=8,4,2,1 MB_BATCHES=1024,4096,8192,16384,32768,65536 python profiles/tools/gpu_microbench.py iiwa planar 2>&1 | grep -v amdgpu.ids > $O/lanes_vs_batch.log
+MB_DYN=rigid_body MB_LANES=4,1 MB_BATCHES=8192,65536 python profiles/tools/gpu_microbench.py iiwa 2>&1 | grep -v amdgpu.ids > $O/rigid_body.log
 # 5. parity calibration
-python tests/gpu_sens_probe.py 4 2048 40 2>&1 | grep -v amdgpu.ids > $O/sens_l4.log
-python tests/gpu_sens_probe.py 8 2048 40 2>&1 | grep -v amdgpu.ids > $O/sens_l8.log
+python profiles/tools/gpu_sens_probe.py 4 2048 40 2>&1 | grep -v amdgpu.ids > $O/sens_l4.log
+python profiles/tools/gpu_sens_probe.py 8 2048 40 2>&1 | grep -v amdgpu.ids > $O/sens_l8.log
 # 6. the bench lines: default, the driver's command, two ranks sharing the GPU over gloo
 python bench.py 2>/dev/null | tail -1 > $O/bench_default.json
 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_driver_cmd.json

@@ -8,9 +8,9 @@ python -m pytest tests -m gpu -q -x 2>&1 | grep -v amdgpu.ids | tail -15 > $O/gp
 tail -3 $O/gpu_suite.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -5 > $O/smoke.log
 tail -1 $O/smoke.log
-MB_DTYPE=f64 MB_WARM=30 MB_ROLLOUT=1 MB_LANES=1,2,4,8 MB_BATCHES=8192 python tests/gpu_microbench.py iiwa 2>&1 | grep -v amdgpu.ids > $O/f64_lanes.log
+MB_DTYPE=f64 MB_WARM=30 MB_ROLLOUT=1 MB_LANES=1,2,4,8 MB_BATCHES=8192 python profiles/tools/gpu_microbench.py iiwa 2>&1 | grep -v amdgpu.ids > $O/f64_lanes.log
 cat $O/f64_lanes.log
-MB_WARM=30 MB_ROLLOUT=1 MB_LANES=4,8,4,8 MB_BATCHES=8192 python tests/gpu_microbench.py planar 2>&1 | grep -v amdgpu.ids > $O/planar_lanes.log
+MB_WARM=30 MB_ROLLOUT=1 MB_LANES=4,8,4,8 MB_BATCHES=8192 python profiles/tools/gpu_microbench.py planar 2>&1 | grep -v amdgpu.ids > $O/planar_lanes.log
 cat $O/planar_lanes.log
 python bench.py 2>$O/bench_default.err | tail -1 > $O/bench_default.json
 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_driver_cmd.json

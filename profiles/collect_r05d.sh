@@ -15,15 +15,15 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_planar -o s -- 
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_circle -o s -- \
     python bench.py --env circle --batch 4096 --steps 300 --warmup 30 --min-time 0.3 --no-cpu-baseline --no-secondary > $O/bench_circle_under_rocprof.log 2>&1
 MB_DYN=rigid_body_ff MB_WARM=60 MB_LANES=4 MB_BATCHES=8192 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_dyn -o s -- \
-    python tests/gpu_microbench.py iiwa > $O/dyn_under_rocprof.log 2>&1
+    python profiles/tools/gpu_microbench.py iiwa > $O/dyn_under_rocprof.log 2>&1
 for W in "0 8192 iiwa reference kinematic" "0 8192 planar reference kinematic" "0 4096 circle reference kinematic" "0 8192 iiwa reference rigid_body_ff"; do
   T=$(echo $W | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$T -o c -- python tests/gpu_pmc_target.py $W > /dev/null 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$T -o c -- python tests/gpu_pmc_target.py $W > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$T -o c -- python profiles/tools/gpu_pmc_target.py $W > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_$T -o c -- python profiles/tools/gpu_pmc_target.py $W > /dev/null 2>&1
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU \
-      SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_sq_$T -o c -- python tests/gpu_pmc_target.py $W > /dev/null 2>&1
+      SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $O/pmc_sq_$T -o c -- python profiles/tools/gpu_pmc_target.py $W > /dev/null 2>&1
 done
-MB_WARM=60 MB_ROLLOUT=1 MB_LANES=0 MB_BATCHES=4096,8192,16384,65536,262144 python tests/gpu_microbench.py iiwa planar 2>&1 | grep -v amdgpu.ids > $O/lanes_vs_batch_reference.log
+MB_WARM=60 MB_ROLLOUT=1 MB_LANES=0 MB_BATCHES=4096,8192,16384,65536,262144 python profiles/tools/gpu_microbench.py iiwa planar 2>&1 | grep -v amdgpu.ids > $O/lanes_vs_batch_reference.log
 cat $O/lanes_vs_batch_reference.log
 python bench.py 2>/dev/null | tail -1 > $O/bench_default.json
 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_driver_cmd.json

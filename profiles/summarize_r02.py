@@ -54,7 +54,7 @@ def main():
         'kernel': 'atacom::k_step<float, Iiwa, 4, true, false> (B=8192)',
         'FETCH_SIZE_KB': f, 'WRITE_SIZE_KB': w, 'hbm_bytes_per_launch': (f + w) * 1024,
         'note': 'round 2; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/collect_r02.sh, '
-                'tests/gpu_pmc_target.py), mean of 20 launches; raw counter x 1024. The gfx950 x2 FETCH_SIZE '
+                'profiles/tools/gpu_pmc_target.py), mean of 20 launches; raw counter x 1024. The gfx950 x2 FETCH_SIZE '
                 'correction of MI355X_MICROARCH.md applies to 16 B/lane streams; these loads are 4 B/lane so the '
                 'raw value is reported. Algorithmic bytes per launch: 400 B x 8192 = 3.28 MB.'}
     json.dump(traffic, open(os.path.join(HERE, 'traffic_iiwa.json'), 'w'), indent=1)

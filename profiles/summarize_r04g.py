@@ -29,7 +29,7 @@ def main():
         json.dump({'kernel': f['_kernel'], 'workload': w, 'FETCH_SIZE_KB': f['FETCH_SIZE'], 'WRITE_SIZE_KB': wr['WRITE_SIZE'],
                    'hbm_bytes_per_launch': tot, 'algorithmic_bytes_per_launch': algo,
                    'note': 'round 4, the build that ships; rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes '
-                           '(profiles/collect_r04g.sh, tests/gpu_pmc_target.py), mean of 20 launches; raw counter x 1024'},
+                           '(profiles/collect_r04g.sh, profiles/tools/gpu_pmc_target.py), mean of 20 launches; raw counter x 1024'},
                   open(os.path.join(HERE, fn), 'w'), indent=1)
         lines.append('| %s | `%s` | %.1f | %.1f | %.0f | %d | %.2f | %.0f | %.0f | %.0f | %.2f | %.1f |' % (
             w, f['_kernel'].replace('void atacom::', '')[:48], f['FETCH_SIZE'], wr['WRITE_SIZE'], tot, algo, tot / algo,

@@ -80,6 +80,6 @@ for form in ('cov','sqrt'):
 print()
 print('A pivot near the tolerance (tol^2 = 2.5e-3) is what is left of O(1) entries after up to five rank-one downdates: in the')
 print('covariance form its relative error is eps / tol^2 (and one sample in 6000 flips a decision), in the square-root form')
-print('eps / tol.  Measured on the GPU (tests/gpu_chart_probe.py, 6000 iiwa systems incl. slack charts and stiff rows, float32')
+print('eps / tol.  Measured on the GPU (profiles/tools/gpu_chart_probe.py, 6000 iiwa systems incl. slack charts and stiff rows, float32')
 print('kernel vs float64 specification): covariance form median 4.3e-6 / p99 3.5e-3 / max 0.98; square-root form median 1.4e-7 /')
 print('p99 4.2e-6 / max 9.5e-5.')

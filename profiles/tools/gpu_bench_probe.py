@@ -1,7 +1,7 @@
-"""Kernel-tuning helper (not a pytest file): the phase probe of tests/gpu_phase_probe.py on the BENCH workload -- feasible
+"""Kernel-tuning helper (not a pytest file): the phase probe of profiles/tools/gpu_phase_probe.py on the BENCH workload -- feasible
 perturbed initial states (bench.feasible_init), random actions, auto-reset, free-running -- over many launches: what a
 launch lasts (HIP events), what its median and its slowest wavefront compute, and (canonical chart) how often the
-data-dependent parts run.  Needs the -DATACOM_TIMESTAMPS build: ATACOM_LIB=build/ts/libatacom_ts.so python tests/gpu_bench_probe.py [lanes]
+data-dependent parts run.  Needs the -DATACOM_TIMESTAMPS build: ATACOM_LIB=build/ts/libatacom_ts.so python profiles/tools/gpu_bench_probe.py [lanes]
 """
 import os, sys
 import numpy as np

@@ -4,8 +4,8 @@ Times the k_chart primitive (one system per lane, 64 per wavefront) on batches i
 mix: plain systems only / one system with a stiff row / several different stiff rows / one system one free coordinate
 short (stage B) / the natural mix of a rollout."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np
 import torch
 from chart_cases import rollout_systems

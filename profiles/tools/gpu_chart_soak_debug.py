@@ -1,12 +1,12 @@
-"""Kernel-debugging helper (not a pytest file): the samples of the canonical-chart float32 soak (tests/gpu_sens_probe.py) whose
+"""Kernel-debugging helper (not a pytest file): the samples of the canonical-chart float32 soak (profiles/tools/gpu_sens_probe.py) whose
 error exceeds the quick sensitivity bound, with what the oracle says about them.
-    [ATACOM_LIB=...] python tests/gpu_chart_soak_debug.py [env] [lanes] [B] [T]"""
+    [ATACOM_LIB=...] python profiles/tools/gpu_chart_soak_debug.py [env] [lanes] [B] [T]"""
 import dataclasses
 import os
 import sys
 import numpy as np
 import torch
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests")      # parity_tools etc. live in tests/ (these probes lived there until round 6)
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle import atacom_scalar as osc, atacom_batched as ob

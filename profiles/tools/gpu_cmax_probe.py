@@ -3,11 +3,11 @@ from?  Replays shard R of the config-5 rehearsal (tests/test_gpu_rollout.py: ben
 finds the (step, environment) of the largest c = max(|f|, g), then teacher-forces the float64 device kernels and the float64
 oracle through the steps before it FROM THE FLOAT32 DEVICE'S OWN STATES: if they produce the same violation from the same
 state, it is the reference algorithm's (the rref tolerance branch leaks), not the kernel's.
-    python tests/gpu_cmax_probe.py [R] [LIB...]"""
+    python profiles/tools/gpu_cmax_probe.py [R] [LIB...]"""
 import os, sys
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 import bench

@@ -1,12 +1,12 @@
-"""Audit helper (not a pytest file): the largest constraint value of the iiwa endurance soak (tests/gpu_long_soak.py, same seeds
+"""Audit helper (not a pytest file): the largest constraint value of the iiwa endurance soak (profiles/tools/gpu_long_soak.py, same seeds
 and action pool) -- where it happens, and whether the float64 oracle, teacher-forced from the device's own states, produces the
 same violation.  Pass 1 finds the window of W steps holding the maximum (statistics read every W steps), pass 2 replays the
 deterministic run to that window and keeps every state of it.
-    python tests/gpu_cmax_soak_probe.py [STEPS] [W]"""
+    python profiles/tools/gpu_cmax_soak_probe.py [STEPS] [W]"""
 import os, sys
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from rl_on_manifold_amd import BatchedAtacomEnv, constraint_terms
 from oracle import atacom_scalar as osc, atacom_batched as ob

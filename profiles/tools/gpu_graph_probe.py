@@ -1,7 +1,7 @@
 """Probe: are the C-ABI launches HIP-graph capturable, and what does a replayed 20-step graph cost per step?"""
 import os, sys, time
 import torch
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests")      # parity_tools etc. live in tests/ (these probes lived there until round 6)
 sys.path.insert(0, os.path.dirname(HERE))
 from rl_on_manifold_amd import BatchedAtacomEnv
 dev = 'cuda:0'

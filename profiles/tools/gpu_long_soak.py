@@ -1,6 +1,6 @@
 """Endurance run (not a pytest file): free-running environments with random actions, auto-reset and randomised resets for
 hundreds of thousands of steps; every CHECK steps the whole persistent state must be finite and the constraint statistics
-are printed.  python tests/gpu_long_soak.py [STEPS] [CHECK]"""
+are printed.  python profiles/tools/gpu_long_soak.py [STEPS] [CHECK]"""
 import sys, time
 import torch
 sys.path.insert(0, '.')

@@ -1,11 +1,11 @@
 """One-off measurement (not a test): float32 HIP vs float64 oracle error of one teacher-forced env step as a function of
 the oracle's decision margins (oracle/atacom_batched.py: track_margins).  Output feeds the bounds asserted in
-tests/test_gpu_parity.py and profiles/r02_parity_margins.md.   python tests/gpu_margin_probe.py [lanes] [B] [T]"""
+tests/test_gpu_parity.py and profiles/r02_parity_margins.md.   python profiles/tools/gpu_margin_probe.py [lanes] [B] [T]"""
 import os
 import sys
 import numpy as np
 import torch
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests")      # parity_tools etc. live in tests/ (these probes lived there until round 6)
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle import atacom_scalar as osc, atacom_batched as ob

@@ -2,7 +2,7 @@
 
 Needs a library built with -DATACOM_TIMESTAMPS (ATACOM_HIPCC_FLAGS=-DATACOM_TIMESTAMPS ATACOM_LIB_OUT=... python -m
 rl_on_manifold_amd.build), whose k_step overwrites obs[:, 0:4] with four 100 MHz wall-clock stamps per environment:
-wave start, state loaded, sub-steps done, stores landed.  Usage: ATACOM_LIB=<that .so> python tests/gpu_phase_probe.py [lanes]
+wave start, state loaded, sub-steps done, stores landed.  Usage: ATACOM_LIB=<that .so> python profiles/tools/gpu_phase_probe.py [lanes]
 """
 import os, sys
 import numpy as np
@@ -16,7 +16,7 @@ env = BatchedAtacomEnv('iiwa', B, device='cuda:0', dtype=torch.float32, lanes_pe
                        chart_mode=os.environ.get('MB_CHART', 'reference'))
 a = torch.zeros((B, 5), device='cuda:0')
 if os.environ.get('MB_RANDOM'):
-    # the states of tests/gpu_microbench.py: perturbed start, random actions, 60 steps in -- constraints become active
+    # the states of profiles/tools/gpu_microbench.py: perturbed start, random actions, 60 steps in -- constraints become active
     gen = torch.Generator(device='cuda:0'); gen.manual_seed(0)
     st = env.get_state(); nq, ng = env.dims['q'], env.dims['g']
     init = torch.zeros((B, env.init_state_dim), device='cuda:0')

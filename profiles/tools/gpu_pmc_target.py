@@ -1,5 +1,5 @@
 """Tiny target for rocprofv3 --pmc passes: a few atacom_step launches.
-    python tests/gpu_pmc_target.py LANES [BATCH] [ENV] [CHART] [DYNAMICS]        (defaults: 0 8192 iiwa reference kinematic)"""
+    python profiles/tools/gpu_pmc_target.py LANES [BATCH] [ENV] [CHART] [DYNAMICS]        (defaults: 0 8192 iiwa reference kinematic)"""
 import sys
 import torch
 sys.path.insert(0, '.')

@@ -1,7 +1,7 @@
 """Run-to-run reproducibility: the same launch on the same state must give bitwise identical results."""
 import os, sys
 import numpy as np, torch
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests")      # parity_tools etc. live in tests/ (these probes lived there until round 6)
 sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
 from rl_on_manifold_amd import BatchedAtacomEnv
 B = 8192

@@ -1,13 +1,13 @@
 """Calibration run behind tests/parity_tools.py (not a test): teacher-forced float32 env steps against the float64 oracle,
 with the oracle's own sensitivity to float32-sized perturbations (inputs + unstructured J_c noise) and its decision
-margins.  Output is pasted into profiles/r02_parity_sensitivity.md.   python tests/gpu_sens_probe.py [lanes] [B] [T]
+margins.  Output is pasted into profiles/r02_parity_sensitivity.md.   python profiles/tools/gpu_sens_probe.py [lanes] [B] [T]
 (MB_CHART=canonical: the opt-in chart, kernel and oracle both -- profiles/r03_sens_soak_canonical_l*.log)"""
 import dataclasses
 import os
 import sys
 import numpy as np
 import torch
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests")      # parity_tools etc. live in tests/ (these probes lived there until round 6)
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle import atacom_scalar as osc, atacom_batched as ob

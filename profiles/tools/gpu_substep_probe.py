@@ -1,6 +1,6 @@
 """Diagnostic (not a test): atacom_step time as a function of the number of physics sub-steps -- separates the per-launch
 cost (dispatch, state load / store, COLD instruction fetch) from the per-sub-step cost.
-    python tests/gpu_substep_probe.py [reference|canonical] [lanes] [batch]"""
+    python profiles/tools/gpu_substep_probe.py [reference|canonical] [lanes] [batch]"""
 import sys
 import torch
 sys.path.insert(0, '.')

@@ -19,7 +19,7 @@ EXPORTS = ['atacom_snapshot_bytes', 'atacom_snapshot_save', 'atacom_snapshot_res
            'atacom_inverse_dynamics', 'atacom_forward_dynamics', 'atacom_default_config', 'atacom_get_dims', 'atacom_create', 'atacom_destroy', 'atacom_reset',
            'atacom_step', 'atacom_rollout', 'atacom_get_stats', 'atacom_get_state', 'atacom_set_state',
            'atacom_nullspace', 'atacom_constraint_terms', 'atacom_step_masked', 'atacom_canonical_mu', 'atacom_last_error', 'atacom_version', 'atacom_get_lanes',
-           'atacom_get_filter_state', 'atacom_set_filter_state', 'atacom_set_seed']
+           'atacom_get_filter_state', 'atacom_set_filter_state', 'atacom_set_seed', 'atacom_get_policy_lanes']
 
 
 class AtacomConfig(C.Structure):
@@ -92,6 +92,7 @@ def load():
     lib.atacom_rollout_packed.argtypes = [vp, i32, vp, C.POINTER(AtacomMlp), vp, vp, i32, vp]
     lib.atacom_get_stats.argtypes = [vp, C.POINTER(C.c_double * 3), i32, vp]
     lib.atacom_get_lanes.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.atacom_get_policy_lanes.argtypes = [vp, C.POINTER(i32)]
     lib.atacom_set_seed.argtypes = [vp, i32]
     lib.atacom_get_state.argtypes = [vp, vp, vp]
     lib.atacom_set_state.argtypes = [vp, vp, vp]

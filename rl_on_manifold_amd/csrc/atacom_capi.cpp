@@ -86,15 +86,20 @@ constexpr int kStatBlocks = 256;
 // 8 lanes up to 8192 (19.7 us per step), 4 up to 16384 (21.5), 2 up to 32768 (25.7), one beyond (28.8 at 65536); planar like
 // the reference chart's kernels (single steps at 8192: 13.8 us with 4 lanes, 14.2 with 2, 15.7 with one;
 // profiles/r03_lanes_vs_batch_canonical.log, r03_ab_rowslots.log, r03_ab_stage_a.log).
-enum { KIND_STEP = 0, KIND_ROLLOUT = 1 };
+enum { KIND_STEP = 0, KIND_ROLLOUT = 1, KIND_MLP = 2 };     // = atacom_ops_impl.h
 int pick_lanes_raw(const atacom_config& c, int kind) {
     if (c.lanes_per_env == 1 || c.lanes_per_env == 2 || c.lanes_per_env == 4 || c.lanes_per_env == 8)
         return c.lanes_per_env;
     if (c.dtype == ATACOM_F64) {
-        // float64 (the parity build, and the bench's reference-precision record): one environment per lane, except iiwa up
-        // to 8192 environments, where the 8-lane kernels are 30 % faster (112.7 against 161.3 us per step, T-step 94.4
-        // against 155.8: profiles/r05_f64_lanes.log) -- the same "widest mapping whose waves find a SIMD each" rule
-        if (c.env_id == ATACOM_ENV_IIWA && c.chart_mode == 0 && c.batch <= 8192) return 8;
+        // float64 (the reference's precision: the parity build and the bench's float64 records).  Same rule as float32 --
+        // the widest instantiated mapping whose waves still find a SIMD each -- on the float64 census (1, 4 and, iiwa, 8 lanes;
+        // atacom_ops_impl.h: has_mapping).  Measured at 8192 environments with the solver inlined (round 6,
+        // profiles/r06_f64_lanes_inlined.log): iiwa 50.2 us per step on 8 lanes, 53.2 on 4, 161.9 on one (T-step 44.8 / 52.3 /
+        // 158.3); planar 20.2 on 4 lanes, 25.2 on one (T-step 17.7 / 22.2)
+        if (c.chart_mode == 0 || c.env_id == ATACOM_ENV_IIWA) {
+            if (c.env_id == ATACOM_ENV_IIWA) return c.batch <= 8192 ? 8 : (c.batch <= 16384 ? 4 : 1);
+            if (c.env_id == ATACOM_ENV_PLANAR) return c.batch <= 16384 ? 4 : 1;
+        }
         return 1;
     }
     if (c.chart_mode == 1) {
@@ -124,12 +129,6 @@ int pick_lanes_raw(const atacom_config& c, int kind) {
     }
     return 1;                                                              // circle: launch-bound either way
 }
-int pick_lanes(const atacom_config& c, int kind) {
-    const int l = pick_lanes_raw(c, kind);
-    if (c.dynamics_mode != 0) return l >= 4 ? 4 : 1;
-    return l;
-}
-
 // default initial state rows: [q, dq, puck(6)]
 void default_init_row(int env_id, int task, std::vector<double>& row) {
     double puck[6] = {-0.4, 0.0, 0.0, 0.0, 0.0, 0.0};         // centre of hit_range, env_hitting.py:11,27
@@ -175,16 +174,20 @@ struct SnapHeader {
     int32_t struct_size, env_id, dtype, batch, n_planes, n_iplanes, task, elem;
     int32_t step_lanes, rollout_lanes;      // the kernel mappings of the handle that wrote the image (summation order: a
                                             // replay is bit for bit only on the same mappings -- atacom_snapshot_restore)
-    uint32_t pad[4];
+    uint32_t version;                       // format of the image (kSnapVersion); images of library <= 0.5 carry 0 here
+    int32_t seed;                           // the writer's generator key (cfg.seed / atacom_set_seed): restored with the state
+    uint32_t pad[2];
 };
 static_assert(sizeof(SnapHeader) == 64, "snapshot header is 64 bytes");
 constexpr uint32_t kSnapMagic = 0x4e535441u;      // "ATSN"
+constexpr uint32_t kSnapVersion = 2;              // 1: library 0.4 (no mappings in the header, never tagged); 2: library 0.6
 static SnapHeader snap_header(const atacom_handle* h) {
     SnapHeader s;
     std::memset(&s, 0, sizeof(s));
     s.magic = kSnapMagic; s.header_bytes = (uint32_t)sizeof(SnapHeader);
     s.struct_size = h->cfg.struct_size; s.env_id = h->cfg.env_id; s.dtype = h->cfg.dtype; s.batch = h->cfg.batch;
     s.n_planes = h->ops->n_planes; s.n_iplanes = h->ops->n_iplanes; s.task = h->cfg.task; s.elem = (int32_t)h->ops->elem;
+    s.version = kSnapVersion; s.seed = h->cfg.seed;
     return s;                                   // (the lanes fields are filled by the callers: see snap_header_with_lanes)
 }
 
@@ -193,6 +196,7 @@ struct Stepper {
     decltype(atacom::VariantOps::step) step;
     decltype(atacom::VariantOps::rollout) rollout;
     decltype(atacom::VariantOps::rollout_mlp) rollout_mlp;
+    decltype(atacom::VariantOps::lanes_run) lanes_run;
 };
 static Stepper stepper(const atacom_handle* h) {
     const atacom_config& c = h->cfg;
@@ -200,15 +204,22 @@ static Stepper stepper(const atacom_handle* h) {
     if (c.dynamics_mode != 0) v = atacom::ops_iiwa_dyn_variant(c.dtype, c.chart_mode);
     else if (c.obs_noise || c.obs_delay || c.env_noise) v = atacom::ops_noise(c.env_id, c.dtype, c.chart_mode);
     else if (c.chart_mode == 1) v = atacom::ops_chart(c.env_id, c.dtype);
-    if (v) return {v->step, v->rollout, v->rollout_mlp};
-    return {h->ops->step, h->ops->rollout, h->ops->rollout_mlp};
+    if (v) return {v->step, v->rollout, v->rollout_mlp, v->lanes_run};
+    return {h->ops->step, h->ops->rollout, h->ops->rollout_mlp, h->ops->lanes_run};
 }
 
+// The mapping each kind of launch REALLY runs on: the request (cfg.lanes_per_env, a calibrated / adopted override, or the
+// static policy) narrowed to the instantiated mappings of the handle's kernel variant (atacom_ops_impl.h: has_mapping) --
+// what atacom_get_lanes / atacom_get_policy_lanes report and the snapshot header records.
 static int step_lanes(const atacom_handle* h) {
-    return h->step_lanes ? h->step_lanes : pick_lanes(h->cfg, KIND_STEP);
+    return stepper(h).lanes_run(KIND_STEP, h->step_lanes ? h->step_lanes : pick_lanes_raw(h->cfg, KIND_STEP));
 }
 static int rollout_lanes(const atacom_handle* h) {
-    return h->rollout_lanes ? h->rollout_lanes : pick_lanes(h->cfg, KIND_ROLLOUT);
+    return stepper(h).lanes_run(KIND_ROLLOUT, h->rollout_lanes ? h->rollout_lanes : pick_lanes_raw(h->cfg, KIND_ROLLOUT));
+}
+// the policy kernel follows the T-step mapping where it has that form (float64: quad or lane; float32 8 lanes: matrix cores)
+static int policy_lanes(const atacom_handle* h) {
+    return stepper(h).lanes_run(KIND_MLP, h->rollout_lanes ? h->rollout_lanes : pick_lanes_raw(h->cfg, KIND_ROLLOUT));
 }
 static SnapHeader snap_header_with_lanes(const atacom_handle* h) {
     SnapHeader s = snap_header(h);
@@ -318,7 +329,7 @@ static int check_mlp(const atacom_handle* h, const atacom_mlp* net, const char* 
 extern "C" {
 
 const char* atacom_last_error(void) { return g_err.c_str(); }
-const char* atacom_version(void) { return "atacom_hip 0.5 (gfx950)"; }
+const char* atacom_version(void) { return "atacom_hip 0.6 (gfx950)"; }
 
 int atacom_get_dims(int32_t env_id, atacom_dims* out) {
     const atacom::EnvOps* ops = get_ops(env_id, ATACOM_F32);
@@ -422,6 +433,7 @@ int atacom_create(const atacom_config* cfg, int device, atacom_handle** out) {
     HIP_TRY(guard.err);
     atacom_handle* h = new atacom_handle();
     h->cfg = *cfg;
+    h->cfg.seed = cfg->seed & 0x7fffffff;       // as atacom_set_seed stores it
     h->device = device;
     h->ops = ops;
     h->f = nullptr; h->ip = nullptr; h->partial_dev = nullptr; h->partial_host = nullptr;
@@ -550,11 +562,11 @@ int atacom_rollout_mlp(atacom_handle* h, int32_t n_steps, const atacom_mlp* net,
     if (!d_obs || !d_actions || !d_reward || !d_absorbing || !d_last)
         return fail(ATACOM_E_INVALID, "atacom_rollout_mlp: all output buffers except d_next_obs are required");
     ON_DEVICE(h);
-    const int rc = stepper(h).rollout_mlp(h->cfg, rollout_lanes(h), n_steps, *net, h->f, h->ip, d_noise, d_obs,
+    const int rc = stepper(h).rollout_mlp(h->cfg, policy_lanes(h), n_steps, *net, h->f, h->ip, d_noise, d_obs,
                                        d_next_obs, d_actions, d_reward, d_absorbing, d_last, nullptr, 0,
                                        (hipStream_t)stream);
     if (rc != ATACOM_OK)
-        return fail(ATACOM_E_UNSUPPORTED, "atacom_rollout_mlp: only planar / iiwa with hidden = 64 are compiled in");
+        return fail(ATACOM_E_UNSUPPORTED, "atacom_rollout_mlp: only planar / iiwa with hidden = 64 are compiled in (not: the canonical chart together with noise options / rigid-body mode; float64: reference chart, kinematic, no noise options)");
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
 }
@@ -575,11 +587,11 @@ int atacom_rollout_packed(atacom_handle* h, int32_t n_steps, const void* d_actio
     } else {
         const int vrc = check_mlp(h, net, "atacom_rollout_packed");
         if (vrc != ATACOM_OK) return vrc;
-        const int rc = stepper(h).rollout_mlp(h->cfg, rollout_lanes(h), n_steps, *net, h->f, h->ip, d_noise, nullptr,
+        const int rc = stepper(h).rollout_mlp(h->cfg, policy_lanes(h), n_steps, *net, h->f, h->ip, d_noise, nullptr,
                                               nullptr, nullptr, nullptr, nullptr, nullptr, d_records, record_batch_stride,
                                               (hipStream_t)stream);
         if (rc != ATACOM_OK)
-            return fail(ATACOM_E_UNSUPPORTED, "atacom_rollout_packed: only planar / iiwa with hidden = 64 are compiled in");
+            return fail(ATACOM_E_UNSUPPORTED, "atacom_rollout_packed: only planar / iiwa with hidden = 64 are compiled in (not: the canonical chart together with noise options / rigid-body mode; float64: reference chart, kinematic, no noise options)");
     }
     HIP_TRY(hipGetLastError());
     return ATACOM_OK;
@@ -587,7 +599,10 @@ int atacom_rollout_packed(atacom_handle* h, int32_t n_steps, const void* d_actio
 
 int atacom_set_seed(atacom_handle* h, int32_t seed) {
     if (!h) return fail(ATACOM_E_INVALID, "atacom_set_seed: null handle");
+    ON_DEVICE(h);
     h->cfg.seed = seed & 0x7fffffff;        // kernels receive the configuration by value with every launch
+    const SnapHeader now = snap_header_with_lanes(h);      // the snapshot header carries the key: keep its device copy current
+    HIP_TRY(hipMemcpy(h->snap_dev, &now, sizeof(now), hipMemcpyHostToDevice));
     return ATACOM_OK;
 }
 
@@ -595,6 +610,12 @@ int atacom_get_lanes(const atacom_handle* h, int32_t* out_step_lanes, int32_t* o
     if (!h) return fail(ATACOM_E_INVALID, "atacom_get_lanes: null handle");
     if (out_step_lanes) *out_step_lanes = step_lanes(h);
     if (out_rollout_lanes) *out_rollout_lanes = rollout_lanes(h);
+    return ATACOM_OK;
+}
+
+int atacom_get_policy_lanes(const atacom_handle* h, int32_t* out_policy_lanes) {
+    if (!h || !out_policy_lanes) return fail(ATACOM_E_INVALID, "atacom_get_policy_lanes: null argument");
+    *out_policy_lanes = policy_lanes(h);
     return ATACOM_OK;
 }
 
@@ -667,10 +688,17 @@ int atacom_snapshot_restore(atacom_handle* h, const void* d_image, void* stream)
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     const SnapHeader want = snap_header_with_lanes(h);
     SnapHeader got = *(const SnapHeader*)h->snap_host;
-    const int img_step = got.step_lanes, img_roll = got.rollout_lanes;
+    if (got.magic != kSnapMagic) return fail(ATACOM_E_INVALID, "atacom_snapshot_restore: not a snapshot image (bad magic)");
+    if (got.version != kSnapVersion) {
+        char msg[200];
+        std::snprintf(msg, sizeof(msg), "atacom_snapshot_restore: image format %u, this library reads format %u (images do not "
+                      "travel between library versions: re-create the checkpoint)", got.version, kSnapVersion);
+        return fail(ATACOM_E_INVALID, msg);
+    }
+    const int img_step = got.step_lanes, img_roll = got.rollout_lanes, img_seed = got.seed;
     got.step_lanes = want.step_lanes; got.rollout_lanes = want.rollout_lanes;       // compared separately below
+    got.seed = want.seed;                                                           // adopted below
     if (std::memcmp(&got, &want, sizeof(SnapHeader)) != 0) {
-        if (got.magic != kSnapMagic) return fail(ATACOM_E_INVALID, "atacom_snapshot_restore: not a snapshot image (bad magic)");
         char msg[256];
         std::snprintf(msg, sizeof(msg), "atacom_snapshot_restore: the image belongs to another handle shape (env %d dtype %d batch %d "
                       "task %d, %d + %d fields per env; this handle: env %d dtype %d batch %d task %d, %d + %d)", got.env_id, got.dtype,
@@ -678,21 +706,31 @@ int atacom_snapshot_restore(atacom_handle* h, const void* d_image, void* stream)
                       want.n_planes, want.n_iplanes);
         return fail(ATACOM_E_INVALID, msg);
     }
+    bool header_changed = false;
+    if (img_seed != h->cfg.seed) {
+        // the generator key is part of the state a replay depends on (random_init, obs_noise, env_noise draws): the image's
+        // seed replaces the handle's, like atacom_set_seed would (launches captured in a HIP graph keep theirs)
+        h->cfg.seed = img_seed;
+        header_changed = true;
+    }
     if (img_step != want.step_lanes || img_roll != want.rollout_lanes) {
         // The image was written by a handle running other kernel mappings (the state itself does not depend on them).  A
         // handle that left the choice to the library (lanes_per_env = 0) ADOPTS the image's mappings, so that "restore, repeat
         // the calls" reproduces the writer's bits in another process or on another box; a handle with a named mapping keeps
-        // it.  Mappings this handle's kernel variant does not have (rigid body: lane / quad only; float64: lane) are clamped
-        // the way the policy clamps them.
+        // it.  Mappings this handle's kernel variant does not have are narrowed the way every request is (step_lanes()).
+        // Launches already captured in a HIP graph keep the mapping they were captured with, and a RolloutCollector built
+        // before the restore refuses to collect on changed mappings (rollout.py).
         auto ok = [](int l) { return l == 1 || l == 2 || l == 4 || l == 8; };
         if (!ok(img_step) || !ok(img_roll)) return fail(ATACOM_E_INVALID, "atacom_snapshot_restore: corrupt image header (lanes)");
         if (h->cfg.lanes_per_env == 0) {
-            atacom_config probe = h->cfg;
-            probe.lanes_per_env = img_step; h->step_lanes = pick_lanes(probe, KIND_STEP);
-            probe.lanes_per_env = img_roll; h->rollout_lanes = pick_lanes(probe, KIND_ROLLOUT);
-            const SnapHeader now = snap_header_with_lanes(h);
-            HIP_TRY(hipMemcpy(h->snap_dev, &now, sizeof(now), hipMemcpyHostToDevice));
+            h->step_lanes = img_step;
+            h->rollout_lanes = img_roll;
+            header_changed = true;
         }
+    }
+    if (header_changed) {
+        const SnapHeader now = snap_header_with_lanes(h);
+        HIP_TRY(hipMemcpy(h->snap_dev, &now, sizeof(now), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMemcpyAsync(h->f, img + sizeof(SnapHeader), nf, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     HIP_TRY(hipMemcpyAsync(h->ip, img + sizeof(SnapHeader) + snapshot_float_bytes(h), sizeof(int) * h->ops->n_iplanes * B,

@@ -24,7 +24,7 @@
 
 namespace atacom {
 
-// tuning build only (tests/gpu_phase_probe.py): how often a wavefront went through the data-dependent parts of the chart --
+// tuning build only (profiles/tools/gpu_phase_probe.py): how often a wavefront went through the data-dependent parts of the chart --
 // [0] trips of the stiff-row loop, [1] trips of slack stage A, [2] slack stage B
 #ifdef ATACOM_TIMESTAMPS
 #define ATACOM_DBG_PARAM , int (&dbg)[3]
@@ -149,7 +149,7 @@ __device__ __forceinline__ T lane_pick(Z&& z, const unsigned low) {
 // for a missing free coordinate -- touch ONE row per environment, a different one in each.  Written per row (static_for
 // over the rows, each under a wave-uniform ballot) a wavefront runs one step per DISTINCT row among its environments; per
 // lane (trip n: every lane works on ITS n-th row, gathered by lane_row) it is one trip, rarely two.  Measured on
-// constraint-active iiwa states (tests/gpu_phase_probe.py, path counters of the tuning build; 8192 environments, 4 lanes):
+// constraint-active iiwa states (profiles/tools/gpu_phase_probe.py, path counters of the tuning build; 8192 environments, 4 lanes):
 // a trip of the per-row slack scan cost 2.6 us (all 11 columns evaluated for every lane) and the slowest wavefronts of a
 // launch -- four trips -- set its duration, 33 us against 15 us on quiet states.
 template <typename T, typename E, typename F>
@@ -333,7 +333,7 @@ __device__ __forceinline__ void canonical_mu(const T (&A)[E::NC][E::NQ], const T
         const bool acc = (n_acc < NK) && (dj > tol2);
         // alpha[n_acc] as a one-hot blend: written as a select chain the optimiser turns it into a dynamically indexed
         // private array, promotes that to LDS, and -- to address it -- reads the workgroup size from the AQL dispatch packet
-        // in HOST memory: 2 us per wave alone, up to 13 us with a full launch queueing for it (tests/gpu_phase_probe.py)
+        // in HOST memory: 2 us per wave alone, up to 13 us with a full launch queueing for it (profiles/tools/gpu_phase_probe.py)
         T tv = T(0);
 #pragma unroll
         for (int i = 0; i < NK; ++i) tv = num<T>::fma((n_acc == i) ? T(1) : T(0), alpha[i], tv);
@@ -773,7 +773,7 @@ __device__ __forceinline__ void canonical_mu_group(const T (&A)[E::NC][E::NQ], c
         const bool acc = (n_acc < NK) && (dj > tol2);
         // alpha[n_acc] as a one-hot blend: written as a select chain the optimiser turns it into a dynamically indexed
         // private array, promotes that to LDS, and -- to address it -- reads the workgroup size from the AQL dispatch packet
-        // in HOST memory: 2 us per wave alone, up to 13 us with a full launch queueing for it (tests/gpu_phase_probe.py)
+        // in HOST memory: 2 us per wave alone, up to 13 us with a full launch queueing for it (profiles/tools/gpu_phase_probe.py)
         T tv = T(0);
 #pragma unroll
         for (int i = 0; i < NK; ++i) tv = num<T>::fma((n_acc == i) ? T(1) : T(0), alpha[i], tv);

@@ -1171,7 +1171,7 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_step(const Params<T> P, T* __r
     const int lq = gt % LANES;
     if (b >= B) return;
     const EnvRef<T, NOISE> ref{f, ip, B, b, true};
-#ifdef ATACOM_TIMESTAMPS        // tuning build only (tests/gpu_phase_probe.py): 100 MHz wall-clock stamps per phase
+#ifdef ATACOM_TIMESTAMPS        // tuning build only (profiles/tools/gpu_phase_probe.py): 100 MHz wall-clock stamps per phase
     const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
 #endif
     EnvState<T, E> st;
@@ -1408,7 +1408,10 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
         // (one environment per lane with the network's four GEMM blocks live is the one kernel at the edge of the register
         // file: with the G(0) hoist its spills move INTO the sub-step loop -- 59.6 -> 79.5 us per step, measured -- so it
         // keeps the un-hoisted solver)
-        env_step<T, E, LANES, HOLD, DYN, (LANES > 1), CHART, THREADS, /*PARKDYN*/ DYN>(P, st, act, out, lq, ref);
+#ifndef ATACOM_MLP_PARK
+#define ATACOM_MLP_PARK 1           // -DATACOM_MLP_PARK=0: the build that shows the defect described at env_step (PARKDYN)
+#endif
+        env_step<T, E, LANES, HOLD, DYN, (LANES > 1), CHART, THREADS, /*PARKDYN*/ DYN && ATACOM_MLP_PARK>(P, st, act, out, lq, ref);
         if (lq == 0 && valid) {
             if (rec) {
                 write_obs<T, E>(P, st, rrow + R::NOBS, ref);

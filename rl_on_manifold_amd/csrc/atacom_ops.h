@@ -34,6 +34,8 @@ struct EnvOps {
                   hipStream_t s);
     // obs_delay: the low-pass state [batch, 3 + nq] (planar / iiwa; no-op otherwise); set != 0 writes it
     void (*filter_io)(const atacom_config&, void* f, void* buf, int set, hipStream_t s);
+    // the mapping a request for `lanes` really runs on (kind: 0 step, 1 T-step, 2 policy kernel; atacom_ops_impl.h: has_mapping)
+    int (*lanes_run)(int kind, int lanes);
 };
 
 // The three stepping entry points of a kernel variant other than the default one (atacom_ops_impl.h: Variant)
@@ -48,6 +50,7 @@ struct VariantOps {
     // the canonical chart as a primitive: A [n, c, q], s [n, g], y [n, c], alpha [n, k] -> mu [n, q + g]
     void (*chart_mu)(int n, const void* A, const void* sl, const void* y, const void* alpha, double tol, void* mu,
                      hipStream_t s);
+    int (*lanes_run)(int kind, int lanes);
 };
 // canonical-chart kernels (cfg.chart_mode = 1) of circle / planar / iiwa: atacom_chart.hip, atacom_chart_iiwa.hip
 const VariantOps* ops_chart(int env_id, int dtype);

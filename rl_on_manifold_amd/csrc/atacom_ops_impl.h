@@ -39,6 +39,36 @@ static Params<T> make_params(const atacom_config& c) {
 
 static inline int nblk(int n, int per) { return (n + per - 1) / per; }
 
+// ------------------------------------------------------------------ the census of lane mappings (round 6)
+// Which "lanes per environment" forms of the stepping kernels are INSTANTIATED for a (scalar type, environment, variant).
+// One rule, shared by the dispatchers below and -- through lanes_run in the launch tables -- by the C ABI, so that
+// atacom_get_lanes reports what really runs:
+//   * circle family: one environment per lane only (its step is launch-bound, wider groups were never selected);
+//   * rigid-body kernels: lane and quad (the dynamics are computed redundantly by a group's lanes: wider groups buy nothing);
+//   * float64: 1, 4 and (iiwa) 8 lanes -- the mappings the float64 policy picks (atacom_capi.cpp) and the parity tests hold
+//     to 1e-8; the lane pair exists in float32 only; the float64 policy kernel exists on the quad and the lane;
+//   * float32: 1, 2, 4, 8; the 8-lane policy kernel in its matrix-core form only.
+// A request for a mapping that is not instantiated runs the widest narrower one.
+enum { KIND_STEP = 0, KIND_ROLLOUT = 1, KIND_MLP = 2 };
+template <typename T, typename E, bool DYN>
+constexpr bool has_mapping(int lanes, int kind) {
+    if (lanes == 1) return true;
+    if (E::ID == 0) return false;
+    if (DYN) return lanes == 4;
+    if (std::is_same<T, double>::value) {
+        if (kind == KIND_MLP) return lanes == 4;
+        return lanes == 4 || (lanes == 8 && E::ID == 2);
+    }
+    if (kind == KIND_MLP && lanes == 8) return MlpPath<T, E, 8, 64>::MFMA;
+    return lanes == 2 || lanes == 4 || lanes == 8;
+}
+template <typename T, typename E, bool DYN>
+constexpr int mapping_run(int lanes, int kind) {
+    for (int l = 8; l > 1; l /= 2)
+        if (l <= lanes && has_mapping<T, E, DYN>(l, kind)) return l;
+    return 1;
+}
+
 // The step / rollout / policy-rollout launchers of one kernel VARIANT: kinematic or rigid-body dynamics (DYN, iiwa, row
 // N4), the reference's chart or the canonical one (CHART, atacom_chart.h).  Mappings: LANES in {1, 2, 4, 8}, x HOLD; the
 // rigid-body kernels exist for one environment per lane and per quad (the dynamics are computed redundantly by the lanes of
@@ -47,23 +77,23 @@ static inline int nblk(int n, int per) { return (n + per - 1) / per; }
 template <typename T, typename E, bool DYN, int CHART, bool NOISE = false>
 struct Variant {
     static_assert(!NOISE || (E::PUCK && !DYN), "noise kernels: air-hockey environments, kinematic mode");
-    static constexpr bool WIDE = !DYN;                 // lanes 2 and 8 instantiated
-    template <typename F>
+    // (kind: KIND_STEP / KIND_ROLLOUT share their mappings; the policy kernel has its own list, see rollout_mlp)
+    template <int KIND, typename F>
     static void with_mapping(int lanes, bool hold, F&& f) {
         auto go = [&](auto lc) {
             if (hold) f(lc, std::true_type{});
             else f(lc, std::false_type{});
         };
-        if constexpr (WIDE) {
-            if (lanes == 8) return go(std::integral_constant<int, 8>{});
-            if (lanes == 2) return go(std::integral_constant<int, 2>{});
-        }
-        if (lanes >= 4) return go(std::integral_constant<int, 4>{});
+        const int l = mapping_run<T, E, DYN>(lanes, KIND);
+        if constexpr (has_mapping<T, E, DYN>(8, KIND)) { if (l == 8) return go(std::integral_constant<int, 8>{}); }
+        if constexpr (has_mapping<T, E, DYN>(4, KIND)) { if (l == 4) return go(std::integral_constant<int, 4>{}); }
+        if constexpr (has_mapping<T, E, DYN>(2, KIND)) { if (l == 2) return go(std::integral_constant<int, 2>{}); }
         return go(std::integral_constant<int, 1>{});
     }
+    static int lanes_run(int kind, int lanes) { return mapping_run<T, E, DYN>(lanes, kind); }
     static void step(const atacom_config& c, int lanes, void* f, int* ip, const void* act, void* obs, void* rew,
                      uint8_t* ab, uint8_t* last, const uint8_t* mask, hipStream_t s) {
-        with_mapping(lanes, c.hold_q != 0, [&](auto lc, auto hc) {
+        with_mapping<KIND_STEP>(lanes, c.hold_q != 0, [&](auto lc, auto hc) {
             constexpr int LANES = decltype(lc)::value;
             constexpr bool HOLD = decltype(hc)::value;
             hipLaunchKernelGGL((k_step<T, E, LANES, HOLD, DYN, CHART, NOISE>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)),
@@ -73,7 +103,7 @@ struct Variant {
     }
     static void rollout(const atacom_config& c, int lanes, int n_steps, void* f, int* ip, const void* acts, void* obs,
                         void* nobs, void* rew, uint8_t* ab, uint8_t* last, void* rec, int rec_ld, hipStream_t s) {
-        with_mapping(lanes, c.hold_q != 0, [&](auto lc, auto hc) {
+        with_mapping<KIND_ROLLOUT>(lanes, c.hold_q != 0, [&](auto lc, auto hc) {
             constexpr int LANES = decltype(lc)::value;
             constexpr bool HOLD = decltype(hc)::value;
             hipLaunchKernelGGL((k_rollout<T, E, LANES, HOLD, DYN, CHART, NOISE>), dim3(nblk(c.batch * LANES, BLOCK<LANES>)),
@@ -110,29 +140,17 @@ struct Variant {
         a.log_std_min = (T)net.log_std_min; a.log_std_max = (T)net.log_std_max; a.squash = net.squash;
         a.n_in = net.n_in; a.n_out = net.n_out; a.activation = net.activation;
         if constexpr (E::ID != 0) {
-            if constexpr (WIDE && MlpPath<T, E, 8, 64>::MFMA) {
-                // 8 lanes per environment: matrix-core form only (a wave = one GEMM block of 16 columns, 8 of them
-                // environments); the float64 parity build runs the quad form instead
-                if (lanes == 8) {
-                    if (c.hold_q) launch_mlp<8, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
-                    else launch_mlp<8, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
-                    return ATACOM_OK;
-                }
-            }
-            if (lanes >= 4) {
-                if (c.hold_q) launch_mlp<4, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
-                else launch_mlp<4, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
-                return ATACOM_OK;
-            }
-            if constexpr (WIDE) {
-                if (lanes == 2) {
-                    if (c.hold_q) launch_mlp<2, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
-                    else launch_mlp<2, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
-                    return ATACOM_OK;
-                }
-            }
-            if (c.hold_q) launch_mlp<1, true>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
-            else launch_mlp<1, false>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab, last, rec, rec_ld, s);
+            // float64 (the parity build): the policy kernel exists for the default variant only -- reference chart, kinematic,
+            // no domain randomisation -- which is what the 1e-8 parity tests of row N2 run (tests/test_gpu_parity.py)
+            // float32: every variant except the canonical chart TOGETHER WITH the noise options or the rigid-body mode (two
+            // opt-ins on top of the opt-in chart; never selected by a test or a bench record -- pruned in round 6)
+            if constexpr ((std::is_same<T, double>::value && (DYN || CHART != 0 || NOISE)) || (CHART != 0 && (DYN || NOISE)))
+                return ATACOM_E_UNSUPPORTED;
+            else
+            with_mapping<KIND_MLP>(lanes, c.hold_q != 0, [&](auto lc, auto hc) {
+                launch_mlp<decltype(lc)::value, decltype(hc)::value>(c, n_steps, a, f, ip, noise, obs, nobs, acts, rew, ab,
+                                                                     last, rec, rec_ld, s);
+            });
         }
         return ATACOM_OK;
     }
@@ -143,7 +161,7 @@ struct Variant {
                                (const T*)y, (const T*)alpha, (T)tol, (T*)mu);
     }
     static const VariantOps* table() {
-        static const VariantOps ops = {&step, &rollout, &rollout_mlp, &chart_mu};
+        static const VariantOps ops = {&step, &rollout, &rollout_mlp, &chart_mu, &lanes_run};
         return &ops;
     }
 };
@@ -178,18 +196,18 @@ struct Ops {
     }
     static void nullspace(int lanes, int n, const void* Jc, const void* rhs, double tol, void* x, void* nullb,
                           void* rref, hipStream_t s) {
-        if (lanes == 8)
-            hipLaunchKernelGGL((k_nullspace_quad<T, E, 8>), dim3(nblk(n * 8, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,
+        // the lane-group solver as a primitive, on the mappings of the stepping kernels (has_mapping)
+        const int l = mapping_run<T, E, false>(lanes, KIND_STEP);
+        auto quad = [&](auto lc) {
+            constexpr int LN = decltype(lc)::value;
+            hipLaunchKernelGGL((k_nullspace_quad<T, E, LN>), dim3(nblk(n * LN, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,
                                (const T*)rhs, (T)tol, (T*)x, (T*)nullb, (T*)rref);
-        else if (lanes == 4)
-            hipLaunchKernelGGL((k_nullspace_quad<T, E, 4>), dim3(nblk(n * 4, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,
-                               (const T*)rhs, (T)tol, (T*)x, (T*)nullb, (T*)rref);
-        else if (lanes == 2)
-            hipLaunchKernelGGL((k_nullspace_quad<T, E, 2>), dim3(nblk(n * 2, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,
-                               (const T*)rhs, (T)tol, (T*)x, (T*)nullb, (T*)rref);
-        else
-            hipLaunchKernelGGL((k_nullspace<T, E>), dim3(nblk(n, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,
-                               (const T*)rhs, (T)tol, (T*)x, (T*)nullb, (T*)rref);
+        };
+        if constexpr (has_mapping<T, E, false>(8, KIND_STEP)) { if (l == 8) return quad(std::integral_constant<int, 8>{}); }
+        if constexpr (has_mapping<T, E, false>(4, KIND_STEP)) { if (l == 4) return quad(std::integral_constant<int, 4>{}); }
+        if constexpr (has_mapping<T, E, false>(2, KIND_STEP)) { if (l == 2) return quad(std::integral_constant<int, 2>{}); }
+        hipLaunchKernelGGL((k_nullspace<T, E>), dim3(nblk(n, WAVE)), dim3(WAVE), 0, s, n, (const T*)Jc,
+                           (const T*)rhs, (T)tol, (T*)x, (T*)nullb, (T*)rref);
     }
     static void terms(const atacom_config& c, int n, const void* q, const void* dq, void* fun, void* J, void* b,
                       hipStream_t s) {
@@ -202,7 +220,7 @@ struct Ops {
     static const EnvOps* table() {
         static const EnvOps ops = {L::VALUES_PER_ENV, L::ICOUNT, L::STATE_DIM, L::INIT_DIM, E::OBS, E::NQ, E::NF, E::NG, E::NK,
                                    sizeof(T), &V::step, &V::rollout, &V::rollout_mlp, &reset, &fill_init, &clear_stats, &stats,
-                                   &get_state, &set_state, &nullspace, &terms, &filter_io};
+                                   &get_state, &set_state, &nullspace, &terms, &filter_io, &V::lanes_run};
         return &ops;
     }
 };

@@ -269,7 +269,7 @@ class BatchedAtacomEnv:
         """step_into() with its arguments validated ONCE: returns a zero-argument callable that launches atacom_step (or
         atacom_step_masked) on the caller's current stream with these tensors -- for loops that reuse their buffers and are
         bound by the host (CircularMotion: the kernel runs 4 us, five argument checks and the pointer look-ups of
-        step_into cost 3.5 us per call on top of the 5.3 us of the launch itself; tests/gpu_hostpath_probe.py).  The
+        step_into cost 3.5 us per call on top of the 5.3 us of the launch itself; profiles/tools/gpu_hostpath_probe.py).  The
         callable keeps the tensors alive; it must not be used after close()."""
         B = self.batch
         self._check_io(actions, (B, self.dims['null']), self.dtype, 'actions')
@@ -383,8 +383,17 @@ class BatchedAtacomEnv:
 
     @property
     def rollout_lanes_per_env(self):
-        """The kernel mapping of rollout() / rollout_policy() / rollout_packed() (may differ from step()'s)."""
+        """The kernel mapping of rollout() / rollout_packed(actions=...) (may differ from step()'s; the policy kernel's:
+        policy_lanes_per_env)."""
         return self._lanes()[1]
+
+    @property
+    def policy_lanes_per_env(self):
+        """The kernel mapping of rollout_policy() / rollout_packed(policy=...): the T-step mapping where the policy kernel has
+        that form (float64: quad or lane; atacom_get_policy_lanes)."""
+        a = C.c_int32(0)
+        _lib.check(self._lib.atacom_get_policy_lanes(self._h, C.byref(a)))
+        return int(a.value)
 
     def _on_my_device(self, t):
         return t.device.type == 'cuda' and t.device.index == self._dev_index
@@ -428,6 +437,9 @@ class BatchedAtacomEnv:
         return st
 
     def set_state(self, state):
+        """Parity injection of [B, state_dim] (the layout of get_state) -- NOT a checkpoint (snapshot() / restore() are).  On an
+        obs_delay handle this RESTARTS the low-pass behind the observed velocities on the injected state, like a reset does, so
+        get_state -> set_state does not preserve the filter: to inject a filter state call set_filter_state AFTER set_state."""
         st = self._as_dev(state, (self.batch, self.state_dim))
         _lib.check(self._lib.atacom_set_state(self._h, _ptr(st), self._stream()))
 
@@ -448,6 +460,8 @@ class BatchedAtacomEnv:
         return fv
 
     def set_filter_state(self, fv):
+        """obs_delay: inject the low-pass state.  Call it AFTER set_state (which restarts the filter); the other order is
+        overwritten."""
         a = self._as_dev(fv, (self.batch, 3 + self.dims['q']))
         _lib.check(self._lib.atacom_set_filter_state(self._h, _ptr(a), self._stream()))
 

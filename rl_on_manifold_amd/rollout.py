@@ -102,8 +102,8 @@ class RolloutCollector:
         the configuration, include/atacom_hip.h), so this can only fail when a rank was configured differently
         (lanes_per_env, ATACOM_CALIBRATE=1): checked ONCE here, at construction -- one all-gather of three integers,
         never in the data path -- and refused loudly.  Returns [(batch, step_lanes, rollout_lanes)] per rank."""
-        mine = [int(self.env.batch), int(getattr(self.env, 'lanes_per_env', 0)),
-                int(getattr(self.env, 'rollout_lanes_per_env', 0))]
+        mine = self._my_mappings()
+        self._agreed = tuple(mine)
         if self.world == 1:
             return [tuple(mine)]
         dev = getattr(self.env, 'device', torch.device('cpu'))
@@ -123,6 +123,20 @@ class RolloutCollector:
                                  % (first[0], r, b, first[1], first[2], sl, rl))
         return rows
 
+    def _my_mappings(self):
+        return [int(self.env.batch), int(getattr(self.env, 'lanes_per_env', 0)),
+                int(getattr(self.env, 'rollout_lanes_per_env', 0))]
+
+    def _check_mappings_unchanged(self):
+        """A snapshot restore can make a handle ADOPT the image writer's kernel mappings (include/atacom_hip.h:
+        atacom_snapshot_restore).  The agreement above was reached at construction: a rank whose mappings have changed since
+        refuses to collect -- locally, no collective -- until a new collector is built (on every rank)."""
+        now = tuple(self._my_mappings())
+        if now != self._agreed:
+            raise ValueError("this rank's kernel mappings changed after the collector was built (batch, step, rollout lanes "
+                             "%s -> %s; a snapshot restore adopts the image's mappings): build a new RolloutCollector on every "
+                             "rank" % (self._agreed, now))
+
     # ------------------------------------------------------------------ local collection
     def collect_local(self, n_steps, actions=None, policy=None, noise=None, out=None):
         """T = n_steps env steps of the local shard -> packed records [T, Bm, F].
@@ -130,6 +144,7 @@ class RolloutCollector:
         policy = MlpPolicy       : the actor network evaluated inside the rollout kernel, ONE launch (`noise` optional);
         policy = callable        : policy(obs) -> actions, one launch per step (host-driven loop)."""
         env = self.env
+        self._check_mappings_unchanged()
         fused = hasattr(env, 'rollout_packed')
         if fused and actions is not None:
             return env.rollout_packed(actions=actions, out=out, batch_stride=self.Bm)

@@ -56,6 +56,7 @@ def _scenario(spec, init_q, rng):
     return puck
 
 
+@pytest.mark.mapping(name='planar')
 @pytest.mark.parametrize('lanes', [1, 2, 4, 8])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 def test_defend_task_against_oracle(dt, lanes):
@@ -133,7 +134,9 @@ def test_defend_device_random_init_and_rollout_kernel():
     env2.reset()
     for t in range(acts.shape[0]):
         ob2, r2, ab2, info = env2.step(acts[t])
-        assert torch.equal(ob2, out['next_obs'][t]) and torch.equal(r2, out['reward'][t])
+        # two separately compiled kernels (the float64 handle runs the quad mapping since round 6; the compiler contracts their
+        # multiply-adds differently): equal to rounding, flags equal
+        assert torch.allclose(ob2, out['next_obs'][t], rtol=0, atol=1e-10) and torch.allclose(r2, out['reward'][t], rtol=0, atol=1e-10)
         assert torch.equal(ab2, out['absorbing'][t]) and torch.equal(info['last'], out['last'][t])
 
 

@@ -93,19 +93,14 @@ def _aux(o):
     return np.concatenate([o.qx, o.dqx], 1)
 
 
-@pytest.mark.parametrize('mode', ['rigid_body', 'rigid_body_ff'])
-@pytest.mark.parametrize('lanes', [1, 4, 8])
-@pytest.mark.parametrize('dt', ['f64', 'f32'])
-def test_rigid_body_env_step_against_oracle(dt, lanes, mode):
-    """dynamics_mode = 'rigid_body' / 'rigid_body_ff': the whole env step (ATACOM projection, inverse dynamics, effort saturation, servo
-    joints, hybrid forward dynamics, integration) vs the oracle, teacher-forced incl. the servo-joint state."""
+def _rigid_body_env_step(dt, lanes, mode, T):
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_gpu_parity import _full_state
     from parity_tools import SensitivityRecorder
     from rl_on_manifold_amd import BatchedAtacomEnv
     spec = osc.iiwa_spec(dynamics_mode={'rigid_body': 1, 'rigid_body_ff': 2}[mode])
-    B, T = 256, 30
+    B = 256
     env = BatchedAtacomEnv('iiwa', B, device=DEV, dtype=DT[dt], lanes_per_env=lanes, dynamics_mode=mode)
     # the rigid-body kernels exist per lane and per quad: a wider request maps down, and the handle says so
     assert env.lanes_per_env == env.rollout_lanes_per_env == min(lanes, 4)
@@ -144,6 +139,27 @@ def test_rigid_body_env_step_against_oracle(dt, lanes, mode):
     a = rng.uniform(-1, 1, (B, 5))
     d = (kin.step(a)[0] - env.step(a)[0]).abs().max().item()
     assert d > 1e-4
+
+
+@pytest.mark.mapping(name='iiwa', dyn=True)
+@pytest.mark.parametrize('mode', ['rigid_body', 'rigid_body_ff'])
+@pytest.mark.parametrize('lanes', [1, 4])
+@pytest.mark.parametrize('dt', ['f64', 'f32'])
+def test_rigid_body_env_step_against_oracle(dt, lanes, mode):
+    """dynamics_mode = 'rigid_body' / 'rigid_body_ff': the whole env step (ATACOM projection, inverse dynamics, effort saturation, servo
+    joints, hybrid forward dynamics, integration) vs the oracle, teacher-forced incl. the servo-joint state, on both mappings
+    the mode has.  float64: 256 x 30 states at 1e-8.  float32: 256 x 8 states by the sensitivity rule (its host side -- the
+    oracle's rigid-body step under perturbations -- is what takes the time: the 30-step form is the `slow` test below)."""
+    _rigid_body_env_step(dt, lanes, mode, 30 if dt == 'f64' else 8)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize('mode', ['rigid_body', 'rigid_body_ff'])
+@pytest.mark.parametrize('lanes', [1, 4, 8])
+def test_rigid_body_env_step_against_oracle_soak(lanes, mode):
+    """The float32 form of the test above on 256 x 30 states per case (35 - 55 s each, all of it the oracle), incl. a request
+    for 8 lanes (runs the quad)."""
+    _rigid_body_env_step('f32', lanes, mode, 30)
 
 
 def test_rigid_body_rollout_equals_steps_and_keeps_the_constraints():

@@ -127,11 +127,12 @@ def test_each_noise_option_alone_against_oracle(name, opt):
 def test_noise_options_with_refreshed_q_and_canonical_chart(name):
     """hold_q = 0 (the controller re-reads the FILTERED velocities in every sub-step) and the opt-in chart."""
     _teacher_forced(name, 'f64', 4, ALL, hold_q=0)
-    _teacher_forced(name, 'f64', 8, ALL, chart='canonical')
+    _teacher_forced(name, 'f64', 8 if name == 'iiwa' else 4, ALL, chart='canonical')      # (float64 planar: 1 and 4 lanes)
     _teacher_forced(name, 'f64', 1, ALL, chart='canonical', hold_q=0)
 
 
-@pytest.mark.parametrize('lanes', [1, 8])
+@pytest.mark.mapping(dt='f64')
+@pytest.mark.parametrize('lanes', [1, 4, 8])
 @pytest.mark.parametrize('name', ['planar', 'iiwa'])
 def test_noise_free_running_rollout_kernel_equals_single_steps_and_oracle(name, lanes):
     """Free-running with device-side random resets and auto-reset: the T-step kernel (state in registers, filter state and
@@ -166,9 +167,15 @@ def test_noise_free_running_rollout_kernel_equals_single_steps_and_oracle(name, 
         big = e1.rollout(a)
         for t in range(acts.shape[0]):
             ob2, r2, ab2, info = e2.step(a[t])
-            assert torch.equal(ob2, big['next_obs'][t]) and torch.equal(r2, big['reward'][t]), (dt, t)
+            # (bit for bit on the lane and 8-lane mappings; the quad kernels -- added to this test in round 6 -- to rounding: two
+            # separately compiled kernels whose multiply-adds the compiler contracts on its own)
+            tol = 0.0 if lanes != 4 else (1e-10 if dt == 'f64' else 2e-5)
+            assert float((ob2 - big['next_obs'][t]).abs().max()) <= tol and float((r2 - big['reward'][t]).abs().max()) <= tol, (dt, t)
             assert torch.equal(ab2, big['absorbing'][t]) and torch.equal(info['last'], big['last'][t]), (dt, t)
-        assert torch.equal(e1.get_state(), e2.get_state()) and torch.equal(e1.get_filter_state(), e2.get_filter_state())
+        if lanes != 4:
+            assert torch.equal(e1.get_state(), e2.get_state()) and torch.equal(e1.get_filter_state(), e2.get_filter_state())
+        else:
+            assert torch.allclose(e1.get_state(), e2.get_state(), rtol=0, atol=1e-9 if dt == 'f64' else 1e-4)
 
 
 def test_noise_moments_against_the_reference_formulas():

@@ -270,6 +270,7 @@ def _away_reference(chart, B, T):
     return _AWAY_CACHE[chart]
 
 
+@pytest.mark.mapping(name='iiwa')
 @pytest.mark.parametrize('lanes', [1, 2, 4, 8])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 @pytest.mark.parametrize('chart', ['reference', 'canonical'])
@@ -302,7 +303,7 @@ def test_iiwa_step_teacher_forced_away_from_the_planar_pose(chart, dt, lanes):
         print(_followed_chart_report(rec, 'iiwa', lanes))
 
 
-@pytest.mark.parametrize('lanes', [1, 2, 4])
+@pytest.mark.parametrize('lanes', [1])           # the circle family runs one environment per lane (round 6 census)
 def test_circle_hold_flag_is_a_no_op(lanes):
     """CircularMotion has ONE physics sub-step per env step, so hold_q cannot change anything -- but hold_q = 1 selects
     the kernels with the first right reflector hoisted out of the (one-trip) sub-step loop (row 0 of the circle's J_c is
@@ -320,6 +321,7 @@ def test_circle_hold_flag_is_a_no_op(lanes):
             assert (o0 - o1).abs().max() < tol and (r0 - r1).abs().max() < tol, (dt, t)
 
 
+@pytest.mark.mapping(dt='f64')
 @pytest.mark.parametrize('lanes', [1, 2, 4, 8])
 @pytest.mark.parametrize('name', ['planar', 'iiwa'])
 def test_refresh_and_exact_bias_variants_against_oracle(name, lanes):
@@ -448,6 +450,7 @@ def _policy_pair(golden, key, std=0.5, activation='relu'):
     return dev, ora
 
 
+@pytest.mark.mapping(kind='mlp')
 @pytest.mark.parametrize('lanes', [1, 2, 4, 8])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 @pytest.mark.parametrize('name,key', [('iiwa', 'ppo_iiwa'), ('planar', 'sac_planar')])
@@ -487,6 +490,7 @@ def test_policy_rollout_against_oracle(golden, name, key, dt, lanes):
         print(rec.finish('policy %s lanes %d' % (name, lanes)))
 
 
+@pytest.mark.mapping(name='planar', kind='mlp')
 @pytest.mark.parametrize('lanes', [1, 2, 4, 8])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 def test_sac_style_policy_rollout_against_oracle(golden, dt, lanes):
@@ -885,10 +889,12 @@ def test_host_side_error_paths_and_multiple_handles():
         del os.environ['ATACOM_CALIBRATE']
     e = BatchedAtacomEnv('iiwa', 16384, device=DEV)
     assert (e.lanes_per_env, e.rollout_lanes_per_env) == (4, 4)
-    # float64: one environment per lane, except iiwa up to 8192 environments (8 lanes: 30 % faster, profiles/r05_f64_lanes.log)
+    # float64 (round 6, solver inlined: profiles/r06_f64_lanes_inlined.log): the same rule on the float64 census -- iiwa 8 lanes up
+    # to 8192 environments, 4 up to 16384, one beyond; planar 4 up to 16384
     assert BatchedAtacomEnv('iiwa', 64, device=DEV, dtype=torch.float64).lanes_per_env == 8
-    assert BatchedAtacomEnv('iiwa', 16384, device=DEV, dtype=torch.float64).lanes_per_env == 1
-    assert BatchedAtacomEnv('planar', 64, device=DEV, dtype=torch.float64).lanes_per_env == 1
+    assert BatchedAtacomEnv('iiwa', 16384, device=DEV, dtype=torch.float64).lanes_per_env == 4
+    assert BatchedAtacomEnv('iiwa', 16385, device=DEV, dtype=torch.float64).lanes_per_env == 1
+    assert BatchedAtacomEnv('planar', 64, device=DEV, dtype=torch.float64).lanes_per_env == 4
     p8 = BatchedAtacomEnv('planar', 8192, device=DEV)
     assert (p8.lanes_per_env, p8.rollout_lanes_per_env) == (4, 8)          # planar: T-step kernels on 8 lanes (round 5)
     a = torch.full((96, 3), 0.3, device=DEV)
@@ -960,6 +966,7 @@ def test_device_random_init_matches_oracle_generator(name):
     assert not np.allclose(out['obs'][horizon].cpu().numpy()[:, :2], out['obs'][0].cpu().numpy()[:, :2])
 
 
+@pytest.mark.mapping(name='iiwa')
 @pytest.mark.parametrize('lanes', [1, 2, 4, 8])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 def test_chart_on_slack_structured_matrices(dt, lanes):
@@ -1015,6 +1022,7 @@ def test_policy_rollout_matrix_core_path_ragged_batch(golden, name, key):
             assert float((err < 5e-3).float().mean()) >= 0.97, kk       # the rest: rref tolerance flips
 
 
+@pytest.mark.mapping(name='iiwa')           # (its planar cases run on the planar census: a float64 request for 8 lanes runs 4)
 @pytest.mark.parametrize('lanes', [1, 2, 4, 8])
 @pytest.mark.parametrize('dt', ['f64', 'f32'])
 def test_rank_deficient_inputs_stay_finite(golden, dt, lanes):

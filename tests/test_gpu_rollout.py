@@ -392,6 +392,22 @@ def test_bench_spawns_its_own_ranks():
     assert col['two_collections_overlapped_ms'] <= 2.2 * (col['rollout_ms'] + col['allgather_ms'])
 
 
+def test_bench_eight_ranks_control_flow():
+    """the 8-rank line the driver asks for at round end (`bench.py --gpus 8`), executed once before a node
+    appears -- eight ranks over gloo sharing this box's one GPU: the port, the ranks, the barrier-bracketed blocks, the
+    [8, 120, B, 44] layout of config 5's collection and the non-null fields of the all-gather leg."""
+    res = _run_bench(['--gpus', '8', '--batch', '512', '--steps', '10', '--warmup', '2', '--min-time', '0.2'],
+                     env={'BENCH_DIST_BACKEND': 'gloo'})
+    assert res['n_gpus'] == 8 and res['config']['global_batch'] == 8 * 512 and res['scaling'] == 'weak'
+    assert res['value'] > 0 and res['steps'] == 10 and res['warmup'] == 2
+    col = res['collection']
+    assert col['records'] == [8, 120, 512, 44] and col['backend'] == 'gloo'
+    assert col['allgather_ms'] > 0 and col['allgather_GBps_per_rank'] > 0 and col['two_collections_overlapped_ms'] > 0
+    assert col['bytes_received_per_rank'] == 8 * col['bytes_sent_per_rank'] == 8 * 120 * 512 * 44 * 4
+    assert res['roofline']['frac'] > 0 and res['block_ms_p99'] >= res['timing']['block_ms_median']
+    assert 'secondary' not in res and 'cpu_baseline' not in res          # N = 1 extras
+
+
 def test_vectorized_env_core_shaped_loop():
     """The loop a vectorised Core runs (examples/circle_exp.py:26,42,72-73 in batch form): reset_all, step_all until every
     environment delivered an episode (finished ones masked out and frozen), then get_constraints_logs."""
@@ -668,6 +684,77 @@ def test_default_mapping_is_deterministic_across_processes(tmp_path):
         assert torch.equal(x, y)
     auto.restore(image)                                             # and back to the 8-lane writer's mappings
     assert (auto.lanes_per_env, auto.rollout_lanes_per_env) == (8, 8)
+
+
+def test_mapping_census_matches_the_library():
+    """Round 6: which lane mappings are instantiated is ONE rule (csrc/atacom_ops_impl.h: has_mapping); a request for a
+    mapping that does not exist runs the widest narrower one and the handle SAYS so (float64 8-lane policy
+    rollouts silently ran the quad kernel and reported 8).  tests/conftest.py: mapping_exists mirrors the rule for test
+    selection -- held against the library here, for every (environment, dtype, request), step / T-step / policy kernels,
+    kinematic and rigid-body handles."""
+    from conftest import mapping_exists
+    from rl_on_manifold_amd import BatchedAtacomEnv
+
+    def runs(name, dt, lanes, kind, dyn):
+        return max(l for l in (1, 2, 4, 8) if l <= lanes and mapping_exists(name, dt, l, kind, dyn))
+
+    for name in ('circle', 'circle_ec', 'circle_t', 'planar', 'iiwa'):
+        for dt in ('f32', 'f64'):
+            for dyn in ((False, True) if name == 'iiwa' else (False,)):
+                for lanes in (1, 2, 4, 8):
+                    kw = {'dynamics_mode': 'rigid_body_ff'} if dyn else {}
+                    env = BatchedAtacomEnv(name, 64, device=DEV, dtype={'f32': torch.float32, 'f64': torch.float64}[dt],
+                                           lanes_per_env=lanes, **kw)
+                    got = (env.lanes_per_env, env.rollout_lanes_per_env, env.policy_lanes_per_env)
+                    want = (runs(name, dt, lanes, 'step', dyn), runs(name, dt, lanes, 'step', dyn), runs(name, dt, lanes, 'mlp', dyn))
+                    assert got == want, (name, dt, dyn, lanes, got, want)
+                    env.close()
+    # the static policy (lanes_per_env = 0) only ever names instantiated mappings
+    for name, dt, B, want in (('iiwa', 'f64', 8192, (8, 8, 4)), ('iiwa', 'f64', 16384, (4, 4, 4)), ('iiwa', 'f64', 20000, (1, 1, 1)),
+                              ('planar', 'f64', 8192, (4, 4, 4)), ('planar', 'f32', 8192, (4, 8, 8)), ('iiwa', 'f32', 8192, (8, 8, 8)),
+                              ('circle', 'f32', 4096, (1, 1, 1)), ('circle', 'f64', 4096, (1, 1, 1))):
+        env = BatchedAtacomEnv(name, B, device=DEV, dtype={'f32': torch.float32, 'f64': torch.float64}[dt])
+        assert (env.lanes_per_env, env.rollout_lanes_per_env, env.policy_lanes_per_env) == want, (name, dt, B)
+        env.close()
+
+
+def test_snapshot_carries_the_seed_and_a_format_number():
+    """(1) an image of another format is refused as such; (2) the generator key travels with the image -- a handle
+    re-keyed by seed() writes images that replay bit for bit in a handle created with ANOTHER seed; (3) a RolloutCollector
+    built before a restore that changed the mappings refuses to collect."""
+    from rl_on_manifold_amd import BatchedAtacomEnv, AtacomError
+    from rl_on_manifold_amd.rollout import RolloutCollector
+    B, T = 256, 12
+    kw = dict(device=DEV, auto_reset=True, random_init=True, horizon=5, obs_noise=True, env_noise=True)
+    a = BatchedAtacomEnv('planar', B, seed=3, **kw)
+    a.reset()
+    a.seed(12345)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    acts = torch.rand((T, B, 3), device=DEV, generator=g) * 2 - 1
+    a.rollout(acts[:4])
+    img = a.snapshot()
+    want = a.rollout(acts)
+    b = BatchedAtacomEnv('planar', B, seed=99, **kw)               # another key: adopts the image's
+    b.restore(img)
+    got = b.rollout(acts)
+    for k in ('obs', 'next_obs', 'reward', 'last'):
+        assert torch.equal(want[k], got[k]), k
+    # (1) another format number
+    bad = img.clone()
+    bad[48:52] = torch.tensor([0, 0, 0, 0], dtype=torch.uint8, device=DEV)      # SnapHeader.version (csrc/atacom_capi.cpp)
+    with pytest.raises((AtacomError, ValueError), match='image format 0'):
+        b.restore(bad)
+    # (3) the collector's agreement is on the mappings it saw
+    q = BatchedAtacomEnv('iiwa', 512, device=DEV, auto_reset=True, lanes_per_env=4)
+    qimg = q.snapshot()
+    auto = BatchedAtacomEnv('iiwa', 512, device=DEV, auto_reset=True)
+    col = RolloutCollector(auto)
+    col.collect_local(2, actions=torch.zeros((2, 512, 5), device=DEV))
+    auto.restore(qimg)
+    assert auto.lanes_per_env == 4
+    with pytest.raises(ValueError, match='mappings changed'):
+        col.collect_local(2, actions=torch.zeros((2, 512, 5), device=DEV))
+    RolloutCollector(auto).collect_local(2, actions=torch.zeros((2, 512, 5), device=DEV))
 
 
 @pytest.mark.parametrize('mode,lanes', [('kinematic', 1), ('kinematic', 2), ('kinematic', 4), ('kinematic', 8),

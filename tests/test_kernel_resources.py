@@ -16,6 +16,10 @@ LLVM = '/opt/rocm/lib/llvm/bin'
 MAGIC = b'__CLANG_OFFLOAD_BUNDLE__'
 
 
+def so_path(build):
+    return build.LIB
+
+
 def _kernels(tmp, so=None):
     """[(demangled name, LDS bytes, scratch bytes per lane, VGPRs, AGPRs, code bytes)] of every gfx950 kernel in the library."""
     if so is None:
@@ -55,7 +59,16 @@ def _kernels(tmp, so=None):
 @pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, 'llvm-readelf')), reason='needs the ROCm LLVM binutils')
 def test_no_promoted_arrays_and_no_scratch_in_the_production_kernels(tmp_path):
     ks = _kernels(str(tmp_path))
-    assert len(ks) > 400                                     # 3 tasks + 2 circle baselines, 2 dtypes, 4 mappings, 2 charts, ...
+    # the census (round 6): 3 tasks + 2 circle baselines, 2 dtypes, 2 charts, ... on the mappings
+    # csrc/atacom_ops_impl.h: has_mapping instantiates -- it was 678 kernels / 46 MB with every (dtype, task, mapping) product
+    assert 400 < len(ks) < 450, len(ks)
+    from rl_on_manifold_amd import build
+    assert os.path.getsize(so_path(build)) < 32 * 2 ** 20
+    names = {k[0] for k in ks}
+    for gone in ('k_step<double, Circle, 8, true, false, 0, false>', 'k_step<float, Circle, 4, true, false, 0, false>',
+                 'k_step<double, Iiwa, 2, true, false, 0, false>', 'k_step<double, Planar, 8, true, false, 0, false>',
+                 'k_rollout_mlp<double, Iiwa, 2, true, 64, false, 0, false>', 'k_rollout_mlp<double, Iiwa, 4, true, 64, false, 1, false>'):
+        assert gone not in names, gone
     assert any(k[0].startswith('k_step<float, Iiwa, 4, true, false, 0, false>') for k in ks), [k[0] for k in ks][:5]
     # static LDS: the two-stage statistics reduction, and the float32 rigid-body kernels of the reference chart, which park
     # the held solver state across the dynamics (84 values per lane: 21 float4 x threads per workgroup; atacom_kernels.h) --
@@ -99,3 +112,36 @@ def test_no_promoted_arrays_and_no_scratch_in_the_production_kernels(tmp_path):
                 bad.append((name, scratch))
     assert not bad, bad
     assert n_noise == 2 * 2 * 4 * 2 * 2                      # planar + iiwa, step + rollout, 4 mappings, HOLD, 2 charts (float32)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, 'llvm-readelf')), reason='needs the ROCm LLVM binutils')
+def test_float64_kernels_hold_their_arrays_in_registers(tmp_path):
+    """rounds 1 - 5 compiled the lane-group solver of the float64 kernels as real functions; arrays handed
+    over by reference lived in scratch (1.6 - 2.6 KB per lane, 183 of 331 double kernels, 112 us per step on the headline
+    workload).  With the solver inlined (csrc/atacom_quad.h) what is left is genuine register spilling in the iiwa kernels
+    (256 double-width values do not fit where 256 floats do); pinned here:
+      * the float64 step kernel of the mapping the policy picks for the headline workload -- 8 lanes, reference chart, held
+        q -- uses NO scratch;
+      * no float64 kernel outside the iiwa task uses scratch, except the planar one-lane policy kernel;
+      * the lane-group iiwa step / T-step kernels in kinematic mode stay below 800 bytes per lane (spills), i.e. no private
+        array has come back (the smallest array of the solver is 12 doubles x 2 slots = 192 bytes ON TOP of the spills --
+        the outlined build sat at 1584 - 2392)."""
+    ks = _kernels(str(tmp_path))
+
+    def args(name):
+        return [a.strip() for a in name[name.index('<') + 1:name.rindex('>')].split(',')]
+    by = {k[0]: k for k in ks}
+    head = by['k_step<double, Iiwa, 8, true, false, 0, false>']
+    assert head[2] == 0 and head[1] == 0, head
+    bad = []
+    for name, lds, scratch, *_ in ks:
+        if 'double' not in name or not scratch:
+            continue
+        a = args(name)
+        if len(a) < 2 or a[1] != 'Iiwa':
+            if not (name.startswith('k_rollout_mlp<double, Planar, 1,') or (a[1:3] == ['Planar', '1'] and scratch <= 32)):
+                bad.append((name, scratch))
+            continue
+        if name.startswith(('k_step<', 'k_rollout<')) and int(a[2]) > 1 and a[4] == 'false' and scratch > 800:
+            bad.append((name, scratch))
+    assert not bad, bad
