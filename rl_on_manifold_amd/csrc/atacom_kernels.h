@@ -618,10 +618,12 @@ __device__ __forceinline__ void iiwa_prepare_group(const Params<T>& P, const T (
 // THREADS: threads per workgroup of the calling kernel (sizes the LDS slice the rigid-body mode parks its solver state in)
 // PARKDYN (rigid-body mode, lane groups): park the held solver state in LDS across the dynamics.  Since the dynamics run in link
 // coordinates (round 5) the step and rollout kernels fit without it and are 6 % faster (42.7 against 45.6 us per step, quad,
-// 8192 environments).  The policy kernel keeps it: built without, its in-kernel network sees a wrong observation for three
-// of every four environments of a wavefront from the second step on (found by test_policy_rollout_in_rigid_body_mode; the
-// same source with world-coordinate dynamics, or with the parking, is exact -- a register-level effect in the one kernel that
-// holds four GEMM blocks, the solver state and the dynamics at once; cause not isolated, profiles/r05_dyn_mlp_park.md).
+// 8192 environments).  The policy kernel keeps it: built without, hipcc 7.2 places nine live-range copies (v_accvgpr_write)
+// of wave-wide values at the top of the JOIN block of the lane-0-only store region of the step loop, IN FRONT OF the
+// `s_or_b64 exec` that reopens the mask -- three of four lanes then reload stale registers and the in-kernel network sees a
+// wrong bias from the second step on (isolated in round 6: profiles/r06_exec_mask_copies.md; found in round 5 by
+// test_policy_rollout_in_rigid_body_mode).  A compiler defect that depends on register pressure, not on this source: every
+// kernel of the built library is audited for the pattern (tests/test_kernel_resources.py, profiles/tools/exec_restore_audit.py).
 template <typename T, typename E, int LANES, bool HOLD, bool DYN = false, bool HOIST_G0 = true, int CHART = 0,
           int THREADS = BLOCK<LANES>, bool PARKDYN = false, typename Ref>
 __device__ __forceinline__ void env_step(const Params<T>& P, EnvState<T, E>& st, const T (&act)[E::NK],

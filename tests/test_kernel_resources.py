@@ -145,3 +145,22 @@ def test_float64_kernels_hold_their_arrays_in_registers(tmp_path):
         if name.startswith(('k_step<', 'k_rollout<')) and int(a[2]) > 1 and a[4] == 'false' and scratch > 800:
             bad.append((name, scratch))
     assert not bad, bad
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, 'llvm-objdump')), reason='needs the ROCm LLVM binutils')
+def test_no_register_copies_under_a_narrowed_exec_mask(tmp_path):
+    """ADVICE r5 (medium), isolated in round 6 (profiles/r06_exec_mask_copies.md): hipcc 7.2 can place the register allocator's
+    live-range copies (v_accvgpr_write ...) at the top of the JOIN block of a lane-0-only store region, in front of the
+    `s_or_b64 exec, exec, ...` that reopens the mask -- only the lanes that ran the region get their copy, the rest read
+    stale registers afterwards.  That is what fed the in-kernel network of the rigid-body policy kernel a wrong bias in three
+    of four lanes when built without the LDS parking (the flagged kernel is exactly the one that fails on hardware,
+    profiles/r06_nopark_policy_tests.log).  The defect is silent and moves with code generation, so EVERY kernel of the built
+    library is disassembled and audited for the pattern (profiles/tools/exec_restore_audit.py): a join label followed by
+    nothing but vector copies up to the exec restore."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'profiles', 'tools'))
+    from exec_restore_audit import audit_library
+    from rl_on_manifold_amd import build
+    found, n_objects = audit_library(build.build(verbose=False), str(tmp_path), LLVM)
+    assert n_objects >= 13
+    assert not found, [(f[1], [t for _, t in f[4]]) for f in found]
