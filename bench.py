@@ -553,14 +553,15 @@ def main():
     return result
 
 
-def measured_traffic(name, chart='reference', dyn=False, lanes=0):
+def measured_traffic(name, chart='reference', dyn=False, lanes=0, tag=None):
     """HBM bytes per launch of the step kernel at the BASELINE batch, from the committed counter passes (rocprofv3 --pmc
     FETCH_SIZE and --pmc WRITE_SIZE in separate runs of profiles/tools/gpu_pmc_target.py, summarised into profiles/traffic_*.json) --
     NOT measured inside this run: bench.py cannot host the profiler, the line says where the figure comes from
     (`traffic_source`).  Corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE counts a 16 B / lane streaming
     read at half its bytes (128-byte requests tallied at 64), so the fetch side is doubled; WRITE_SIZE is taken as counted.
     Returns {'bytes', 'raw_counter_bytes', 'fetch_kb', 'write_kb', 'source'} or None."""
-    suffix = '_dyn' if dyn else ('_canonical' if chart == 'canonical' else ('_quad' if name == 'iiwa' and lanes == 4 else ''))
+    # tag: another workload of the same task with a counter pass of its own ('f64': the float64 headline, '65536': the saturation batch)
+    suffix = ('_' + tag) if tag else ('_dyn' if dyn else ('_canonical' if chart == 'canonical' else ('_quad' if name == 'iiwa' and lanes == 4 else '')))
     rel = os.path.join('profiles', 'traffic_%s%s.json' % (name, suffix))
     try:
         d = json.load(open(os.path.join(ROOT, rel)))
@@ -675,7 +676,7 @@ def saturation_records(dev, gen, K, W, sync_all, max_over_ranks):
     secs, kern_ms = time_steps(env, acts, K, min(W, 5), 0.4, sync_all, max_over_ranks)
     el = float(np.median(secs))
     c_avg, c_max, c_dq = env.get_constraints_logs()
-    roof, roof_hbm = roofline_objects('iiwa', B, kern_ms, None)
+    roof, roof_hbm = roofline_objects('iiwa', B, kern_ms, measured_traffic('iiwa', tag='65536'))
     out.append({'workload': 'IiwaAirHockey env 7H, batch 65536 on ONE GPU (config 5\'s global batch), single steps',
                 'path': 'atacom_step (1 launch / step) via C ABI', 'value': B * K / el, 'unit': 'env-steps/s',
                 'ms_per_step': el / K * 1e3, 'blocks': len(secs), 'lanes_per_env': env.lanes_per_env,
@@ -722,8 +723,8 @@ def secondary_records(dev, gen, K, W, sync_all, max_over_ranks):
             rec['tstep'] = tstep_record('circle', B, 500, dev, gen)
             # this configuration is bound by the host's launch path, not by the kernel: the fraction above divides by the time
             # between launches; beside it the kernel-only view, from the committed rocprofv3 kernel statistics of this workload
-            k_us = committed_kernel_us('r04_rocprofv3_kernel_stats_circle.csv', 'k_step<float, atacom::Circle') or \
-                committed_kernel_us('r03_rocprofv3_kernel_stats_circle.csv', 'k_step<float, atacom::Circle')
+            k_us = committed_kernel_us('r06_rocprofv3_kernel_stats_circle.csv', 'k_step<float, atacom::Circle') or \
+                committed_kernel_us('r05_rocprofv3_kernel_stats_circle.csv', 'k_step<float, atacom::Circle')
             rec['launch_bound'] = True
             if k_us:
                 rk, _ = roofline_objects(name, B, k_us * 1e-3, measured_traffic(name))
@@ -739,7 +740,7 @@ def secondary_records(dev, gen, K, W, sync_all, max_over_ranks):
     secs, kern_ms = time_steps(env, acts, K, W, 0.7, sync_all, max_over_ranks)
     el = float(np.median(secs))
     c_avg, c_max, c_dq = env.get_constraints_logs()
-    roof, roof_hbm = roofline_objects('iiwa', 8192, kern_ms, None, f64=True)
+    roof, roof_hbm = roofline_objects('iiwa', 8192, kern_ms, measured_traffic('iiwa', tag='f64'), f64=True)
     out.append({'workload': 'IiwaAirHockey env 7H, batch 8192, float64 (the reference\'s precision)', 'dtype': 'f64',
                 'value': 8192 * K / el, 'unit': 'env-steps/s', 'ms_per_step': el / K * 1e3, 'blocks': len(secs),
                 'max_abs_c': c_max, 'c_avg': c_avg, 'c_dq_max': c_dq, 'lanes_per_env': env.lanes_per_env,

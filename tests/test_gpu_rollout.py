@@ -206,6 +206,9 @@ def _explain_cmax(env, init, acts, c_reported):
         assert abs(c_dev - c_orc) < 1e-4 and float((q_dev.double().cpu() - torch.tensor(o.q)).abs().max()) < 1e-4, (t, b, c_dev, c_orc)
 
 
+P999_BOUND, NABOVE_BOUND = 1.0, 10 ** 9          # provisional: set from the first measurement
+
+
 def test_config5_dress_rehearsal_eight_shards_on_one_gpu():
     """BASELINE config 5 at full size, everything but the xGMI hop: 8 engines x 8192 IiwaAirHockey environments on ONE
     device, each rolled out for the full 120-step horizon by one launch straight into ITS block of the final
@@ -238,7 +241,26 @@ def test_config5_dress_rehearsal_eight_shards_on_one_gpu():
     # teacher-forced from the device's own states, produces the same violation step for step.
     assert np.median(stats[:, 1]) < 0.02 and stats[:, 1].max() < 0.15, stats
     assert stats[:, 2].max() <= 1e-4, stats
-    for r in np.nonzero(stats[:, 1] >= 0.05)[0]:
+    # ... and a tight bound on ROBUST statistics of the same quantity (a shard maximum cannot see a regression that
+    # lifts a minority of environments into the 0.02 - 0.05 band): the largest constraint value of every ENVIRONMENT over its 120
+    # steps, recomputed from the recorded joint positions -- its 99.9th percentile over the 65536 environments and the number of
+    # environments above 0.03 (measured round 6: p99.9 = TBD, TBD environments; bounds at ~2 x)
+    from rl_on_manifold_amd import constraint_terms
+    per_env = []
+    for r in range(W):
+        q = data['next_obs'][r][..., 6:12].reshape(-1, 6).contiguous()
+        fun, _, _ = constraint_terms('iiwa', q, torch.zeros_like(q))
+        c = torch.maximum(fun[:, 0].abs(), fun[:, 1:].max(1).values).reshape(T, B)
+        assert abs(float(c.max()) - stats[r, 1]) < 1e-6, (r, float(c.max()), stats[r, 1])      # the same quantity the kernel logged
+        per_env.append(c.max(0).values)
+    per_env = torch.cat(per_env)
+    p999, n_above = float(torch.quantile(per_env, 0.999)), int((per_env > 0.03).sum())
+    print('config 5 per-environment max c: median %.4f p99.9 %.4f max %.4f, %d of %d environments above 0.03'
+          % (float(per_env.median()), p999, float(per_env.max()), n_above, per_env.numel()))
+    assert p999 < P999_BOUND and n_above <= NABOVE_BOUND, (p999, n_above)
+    # the worst shard is always replayed through the float64 oracle from the device's own states, the others above 0.05 too
+    worst = int(np.argmax(stats[:, 1]))
+    for r in sorted(set([worst]) | set(np.nonzero(stats[:, 1] >= 0.05)[0].tolist())):
         _explain_cmax(*shards[r], float(stats[r, 1]))
     # (i) the shard-major buffer, time-majored, IS the single-engine array rollout of every shard
     tm = lay.time_major(data)
