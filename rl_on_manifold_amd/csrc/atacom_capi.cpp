@@ -97,7 +97,9 @@ int pick_lanes_raw(const atacom_config& c, int kind) {
         // profiles/r06_f64_lanes_inlined.log): iiwa 50.2 us per step on 8 lanes, 53.2 on 4, 161.9 on one (T-step 44.8 / 52.3 /
         // 158.3); planar 20.2 on 4 lanes, 25.2 on one (T-step 17.7 / 22.2)
         if (c.chart_mode == 0 || c.env_id == ATACOM_ENV_IIWA) {
-            if (c.env_id == ATACOM_ENV_IIWA) return c.batch <= 8192 ? 8 : (c.batch <= 16384 ? 4 : 1);
+            // (beyond 8192 the quad stays ahead of the lane at every batch -- 104.8 against 248.8 us at 32768, 207 against 305 at 65536,
+            // profiles/r06_f64_lanes_beyond_16384.log: the float64 lane kernel spills 700 registers)
+            if (c.env_id == ATACOM_ENV_IIWA) return c.batch <= 8192 ? 8 : 4;
             if (c.env_id == ATACOM_ENV_PLANAR) return c.batch <= 16384 ? 4 : 1;
         }
         return 1;

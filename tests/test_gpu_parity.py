@@ -890,10 +890,10 @@ def test_host_side_error_paths_and_multiple_handles():
     e = BatchedAtacomEnv('iiwa', 16384, device=DEV)
     assert (e.lanes_per_env, e.rollout_lanes_per_env) == (4, 4)
     # float64 (round 6, solver inlined: profiles/r06_f64_lanes_inlined.log): the same rule on the float64 census -- iiwa 8 lanes up
-    # to 8192 environments, 4 up to 16384, one beyond; planar 4 up to 16384
+    # to 8192 environments, 4 beyond (r06_f64_lanes_beyond_16384.log); planar 4 up to 16384
     assert BatchedAtacomEnv('iiwa', 64, device=DEV, dtype=torch.float64).lanes_per_env == 8
     assert BatchedAtacomEnv('iiwa', 16384, device=DEV, dtype=torch.float64).lanes_per_env == 4
-    assert BatchedAtacomEnv('iiwa', 16385, device=DEV, dtype=torch.float64).lanes_per_env == 1
+    assert BatchedAtacomEnv('iiwa', 40000, device=DEV, dtype=torch.float64).lanes_per_env == 4
     assert BatchedAtacomEnv('planar', 64, device=DEV, dtype=torch.float64).lanes_per_env == 4
     p8 = BatchedAtacomEnv('planar', 8192, device=DEV)
     assert (p8.lanes_per_env, p8.rollout_lanes_per_env) == (4, 8)          # planar: T-step kernels on 8 lanes (round 5)

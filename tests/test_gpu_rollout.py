@@ -732,7 +732,7 @@ def test_mapping_census_matches_the_library():
                     assert got == want, (name, dt, dyn, lanes, got, want)
                     env.close()
     # the static policy (lanes_per_env = 0) only ever names instantiated mappings
-    for name, dt, B, want in (('iiwa', 'f64', 8192, (8, 8, 4)), ('iiwa', 'f64', 16384, (4, 4, 4)), ('iiwa', 'f64', 20000, (1, 1, 1)),
+    for name, dt, B, want in (('iiwa', 'f64', 8192, (8, 8, 4)), ('iiwa', 'f64', 16384, (4, 4, 4)), ('iiwa', 'f64', 20000, (4, 4, 4)),
                               ('planar', 'f64', 8192, (4, 4, 4)), ('planar', 'f32', 8192, (4, 8, 8)), ('iiwa', 'f32', 8192, (8, 8, 8)),
                               ('circle', 'f32', 4096, (1, 1, 1)), ('circle', 'f64', 4096, (1, 1, 1))):
         env = BatchedAtacomEnv(name, B, device=DEV, dtype={'f32': torch.float32, 'f64': torch.float64}[dt])
