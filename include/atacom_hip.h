@@ -176,7 +176,10 @@ int atacom_reset(atacom_handle* h, const uint8_t* d_mask, const void* d_init_sta
 /* AtacomEnvWrapper.step (atacom.py:106-115) for the whole batch: action clip + scale, `substeps` x
  * [step_action_function (atacom.py:123-139) -> dynamics], absorbing / reward / observation, constraint
  * statistics.  d_action [batch, n_null]; d_obs [batch, obs_dim]; d_reward [batch]; d_absorbing [batch]
- * (uint8); d_last [batch] (uint8, may be NULL) = absorbing or step counter reached the horizon. */
+ * (uint8); d_last [batch] (uint8, may be NULL) = absorbing or step counter reached the horizon.
+ * Non-finite actions do not reach the state: the clip to [-1, 1] (atacom.py:107) is IEEE min / max, so +-Inf clip like any
+ * large value and a NaN component acts as -1 (numpy's clip would propagate the NaN into q and poison that environment for
+ * the rest of the episode); other environments of the batch are never affected either way. */
 int atacom_step(atacom_handle* h, const void* d_action, void* d_obs, void* d_reward, uint8_t* d_absorbing,
                 uint8_t* d_last, void* stream);
 

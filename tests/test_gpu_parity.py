@@ -662,6 +662,31 @@ def test_rollout_kernel_equals_step_kernel(name, lanes):
     assert torch.equal(out['obs'][horizon], reset_obs)
 
 
+@pytest.mark.parametrize('dt', ['f64', 'f32'])
+@pytest.mark.parametrize('name', ['circle', 'planar', 'iiwa'])
+def test_non_finite_actions_are_clipped_not_propagated(name, dt):
+    """A batch must survive a policy that emits NaN / Inf for some environments (include/atacom_hip.h: atacom_step): +-Inf clip
+    to +-1, a NaN component acts as -1, the state stays finite, and the other environments are bit-for-bit what they are
+    without the bad rows."""
+    B = 256
+    k = SHAPES[name][2]
+    g = torch.Generator(device=DEV).manual_seed(2)
+    a = (torch.rand((B, k), device=DEV, generator=g) * 2 - 1).to(DT[dt])
+    bad = a.clone()
+    bad[3] = float('nan'); bad[10, 0] = float('inf'); bad[17, k - 1] = float('-inf'); bad[40, 0] = float('nan')
+    repl = bad.clone()
+    repl[3] = -1.0; repl[10, 0] = 1.0; repl[17, k - 1] = -1.0; repl[40, 0] = -1.0
+    e1, e2 = _env(name, B, dt), _env(name, B, dt)
+    for t in range(3):
+        o1, r1, ab1, _ = e1.step(bad)
+        o2, r2, ab2, _ = e2.step(repl)
+        assert torch.isfinite(o1).all() and torch.isfinite(r1).all(), t
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(ab1, ab2), t
+    assert torch.isfinite(e1.get_state()).all() and torch.equal(e1.get_state(), e2.get_state())
+    c = e1.get_constraints_logs()
+    assert all(np.isfinite(c))
+
+
 @pytest.mark.parametrize('lanes', [1, 2, 4, 8])
 @pytest.mark.parametrize('B', [1, 63, 65])
 def test_ragged_batches_and_masked_reset(B, lanes):
