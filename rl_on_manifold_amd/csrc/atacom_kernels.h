@@ -1314,7 +1314,16 @@ __global__ void __launch_bounds__(BLOCK<LANES>) k_rollout(const Params<T> P, int
 // their stores masked off.
 template <typename T, typename E, int LANES, int H>
 struct MlpPath {
-    static constexpr bool MFMA = std::is_same<T, float>::value && H == 64 && E::OBS <= 32 && E::NK <= 8;
+    // 8 lanes per environment: a wave holds 8 environments -- half of the one GEMM block it can fill is padding.  The VALU form
+    // spread over the 8 lanes (8 hidden units per lane, -DATACOM_MLP8_VALU=1) was built and measured against it in round 6:
+    // SLOWER -- iiwa 23.7 against 23.2 us per step, planar 11.7 against 10.9, at 4096 and 8192 environments, three interleaved
+    // runs (profiles/r06_ab_mlp8_valu.log): 560 vector issue slots cost a lone wave more than 100 matrix instructions and two
+    // LDS round trips.  The matrix cores pay even half empty.
+#ifndef ATACOM_MLP8_VALU
+#define ATACOM_MLP8_VALU 0
+#endif
+    static constexpr bool MFMA = std::is_same<T, float>::value && H == 64 && E::OBS <= 32 && E::NK <= 8 &&
+                                 !(LANES == 8 && ATACOM_MLP8_VALU);
     // blocks of 16 environments per wavefront; with 8 lanes per environment a wave holds 8 environments: ONE block whose
     // columns 8..15 are padding (zero observations in, outputs never read -- GEMM columns do not mix)
     static constexpr int NB = (16 * LANES >= WAVE) ? 1 : WAVE / (16 * LANES);
@@ -1335,7 +1344,7 @@ __global__ void __launch_bounds__(256) k_rollout_mlp(const Params<T> P, const Ml
     using L = Planes<E>;
     using R = Record<E>;
     constexpr bool MFMA = MlpPath<T, E, LANES, H>::MFMA;
-    static_assert(LANES <= 4 || MFMA, "8 lanes per environment: matrix-core form only");
+    static_assert(LANES <= 4 || MFMA || (ATACOM_MLP8_VALU && std::is_same<T, float>::value), "8 lanes per environment: float32 only");
     constexpr int THREADS = MlpPath<T, E, LANES, H>::THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* lds = reinterpret_cast<T*>(smem);

@@ -59,7 +59,7 @@ constexpr bool has_mapping(int lanes, int kind) {
         if (kind == KIND_MLP) return lanes == 4;
         return lanes == 4 || (lanes == 8 && E::ID == 2);
     }
-    if (kind == KIND_MLP && lanes == 8) return MlpPath<T, E, 8, 64>::MFMA;
+    if (kind == KIND_MLP && lanes == 8) return MlpPath<T, E, 8, 64>::MFMA || (ATACOM_MLP8_VALU && std::is_same<T, float>::value);
     return lanes == 2 || lanes == 4 || lanes == 8;
 }
 template <typename T, typename E, bool DYN>

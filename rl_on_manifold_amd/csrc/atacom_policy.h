@@ -122,6 +122,15 @@ __device__ __forceinline__ void mlp_gather(const T (&h)[H / LANES], vec2<T> (&fu
     } else if constexpr (LANES == 2) {
 #pragma unroll
         for (int m = 0; m < H / 2; ++m) full[m] = V2{qbcast<0, 2>(h[m]), qbcast<1, 2>(h[m])};
+    } else if constexpr (LANES == 8) {
+        // unit 8 m + l lives in lane l: pair p = 4 m + i holds units (8 m + 2 i, 8 m + 2 i + 1)
+        static_for<0, H / 8>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            full[4 * m + 0] = V2{qbcast<0, 8>(h[m]), qbcast<1, 8>(h[m])};
+            full[4 * m + 1] = V2{qbcast<2, 8>(h[m]), qbcast<3, 8>(h[m])};
+            full[4 * m + 2] = V2{qbcast<4, 8>(h[m]), qbcast<5, 8>(h[m])};
+            full[4 * m + 3] = V2{qbcast<6, 8>(h[m]), qbcast<7, 8>(h[m])};
+        });
     } else {
 #pragma unroll
         for (int m = 0; m < H / 2; ++m) full[m] = V2{h[2 * m], h[2 * m + 1]};
