@@ -96,12 +96,13 @@ int pick_lanes_raw(const atacom_config& c, int kind) {
         // atacom_ops_impl.h: has_mapping).  Measured at 8192 environments with the solver inlined (round 6,
         // profiles/r06_f64_lanes_inlined.log): iiwa 50.2 us per step on 8 lanes, 53.2 on 4, 161.9 on one (T-step 44.8 / 52.3 /
         // 158.3); planar 20.2 on 4 lanes, 25.2 on one (T-step 17.7 / 22.2)
-        if (c.chart_mode == 0 || c.env_id == ATACOM_ENV_IIWA) {
-            // (beyond 8192 the quad stays ahead of the lane at every batch -- 104.8 against 248.8 us at 32768, 207 against 305 at 65536,
-            // profiles/r06_f64_lanes_beyond_16384.log: the float64 lane kernel spills 700 registers)
-            if (c.env_id == ATACOM_ENV_IIWA) return c.batch <= 8192 ? 8 : 4;
-            if (c.env_id == ATACOM_ENV_PLANAR) return c.batch <= 16384 ? 4 : 1;
-        }
+        // (beyond 8192 the iiwa quad stays ahead of the lane at every batch -- 104.8 against 248.8 us at 32768, 207 against 305 at
+        // 65536, profiles/r06_f64_lanes_beyond_16384.log: the float64 lane kernel spills 700 registers.)  Canonical chart
+        // (profiles/r06_f64_lanes_canonical.log): iiwa 35.9 us on 8 lanes, 39.3 on 4, 56.8 on one at 8192; at 32768 the lane
+        // (61.7) is ahead of the quad (72.0); planar 17.8 on 4 lanes against 21.0 at 8192, 32.4 against 22.7 at 32768
+        if (c.env_id == ATACOM_ENV_IIWA)
+            return c.batch <= 8192 ? 8 : ((c.chart_mode == 0 || c.batch <= 16384) ? 4 : 1);
+        if (c.env_id == ATACOM_ENV_PLANAR) return c.batch <= 16384 ? 4 : 1;
         return 1;
     }
     if (c.chart_mode == 1) {
