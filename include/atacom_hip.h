@@ -74,7 +74,7 @@ typedef struct atacom_config {
                               Not every mapping exists for every handle; a request runs on the widest instantiated mapping
                               that is not wider, and atacom_get_lanes reports it: the circle family runs one environment per
                               lane; float64 handles 1, 4 and (iiwa) 8 lanes -- policy: iiwa 8 up to 8192 envs, 4
-                              beyond; planar 4 up to 16384, else 1; the rigid-body kernels 1 and 4; the planar T-step
+                              beyond (canonical chart: 4 up to 16384, else 1); planar 4 up to 16384, else 1; the rigid-body kernels 1 and 4; the planar T-step
                               kernels take 8 lanes up to 8192 envs where single steps stay on 4; the policy kernel
                               (atacom_rollout_mlp) follows the T-step mapping where it has that form (float64: 4 or 1) --
                               atacom_get_policy_lanes. */
