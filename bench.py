@@ -616,13 +616,11 @@ def tstep_record(name, B, T, dev, gen, dtype=None, reps=4, init=True):
     """The T-step kernel (atacom_rollout: state in registers, one launch for T steps of B environments) timed with HIP events
     on the launch stream, with BOTH rooflines.  HBM view: the bytes the launch must move -- actions in, (obs, next_obs,
     reward, absorbing, last) out, per (step, environment); the state itself moves once per launch (counted).  Returns a
-    record dict.  `init`: feasible initial states of the bench protocol (planar / iiwa)."""
+    record dict.  `init`: the initial states of the bench protocol (make_env) instead of the default reset state."""
     import torch
     from rl_on_manifold_amd import BatchedAtacomEnv
     dtype = dtype or torch.float32
-    if init and name != 'circle':
-        env, _, _ = make_env(name, B, dev, gen, dtype=dtype)
-    elif name == 'circle':
+    if init:
         env, _, _ = make_env(name, B, dev, gen, dtype=dtype)
     else:
         env = BatchedAtacomEnv(name, B, device=dev, dtype=dtype, auto_reset=True)

@@ -16,10 +16,6 @@ LLVM = '/opt/rocm/lib/llvm/bin'
 MAGIC = b'__CLANG_OFFLOAD_BUNDLE__'
 
 
-def so_path(build):
-    return build.LIB
-
-
 def _kernels(tmp, so=None):
     """[(demangled name, LDS bytes, scratch bytes per lane, VGPRs, AGPRs, code bytes)] of every gfx950 kernel in the library."""
     if so is None:
@@ -63,7 +59,7 @@ def test_no_promoted_arrays_and_no_scratch_in_the_production_kernels(tmp_path):
     # csrc/atacom_ops_impl.h: has_mapping instantiates -- it was 678 kernels / 46 MB with every (dtype, task, mapping) product
     assert 400 < len(ks) < 450, len(ks)
     from rl_on_manifold_amd import build
-    assert os.path.getsize(so_path(build)) < 32 * 2 ** 20
+    assert os.path.getsize(build.LIB) < 32 * 2 ** 20
     names = {k[0] for k in ks}
     for gone in ('k_step<double, Circle, 8, true, false, 0, false>', 'k_step<float, Circle, 4, true, false, 0, false>',
                  'k_step<double, Iiwa, 2, true, false, 0, false>', 'k_step<double, Planar, 8, true, false, 0, false>',
