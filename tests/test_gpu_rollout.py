@@ -708,6 +708,35 @@ def test_default_mapping_is_deterministic_across_processes(tmp_path):
     assert (auto.lanes_per_env, auto.rollout_lanes_per_env) == (8, 8)
 
 
+@pytest.mark.parametrize('name,B,T', [('circle', 1 << 20, 12), ('planar', 1 << 18, 6), ('iiwa', 1 << 18, 4)])
+def test_saturation_batches_equal_small_batches(name, B, T):
+    """The largest batches the bench line runs (its `saturation` records: a million circle environments, 262144 planar; and
+    262144 iiwa): everything finite, and -- environments being independent -- the first and the last 192 environments of the big
+    launch are bit for bit what a 192-environment engine on the same mapping computes from the same states and actions
+    (index arithmetic at the far end of the buffers)."""
+    from rl_on_manifold_amd import BatchedAtacomEnv
+    g = torch.Generator(device=DEV).manual_seed(4)
+    big = BatchedAtacomEnv(name, B, device=DEV, auto_reset=True, random_init=True, seed=5, horizon=3)
+    assert big.rollout_lanes_per_env == 1
+    big.reset()
+    k = big.dims['null']
+    acts = torch.rand((T, B, k), device=DEV, generator=g) * 2 - 1
+    st0 = big.get_state().clone()
+    out = big.rollout(acts)
+    for key in ('obs', 'next_obs', 'reward'):
+        assert bool(torch.isfinite(out[key]).all()), key
+    assert bool(torch.isfinite(big.get_state()).all())
+    c_avg, c_max, c_dq = big.get_constraints_logs()
+    assert np.isfinite([c_avg, c_max, c_dq]).all() and c_max < 0.5
+    n = 192
+    for sl in (slice(0, n), slice(B - n, B)):
+        small = BatchedAtacomEnv(name, n, device=DEV, auto_reset=False, lanes_per_env=1, horizon=10 ** 6)
+        small.set_state(st0[sl])
+        ref = small.rollout(acts[:2, sl].contiguous())           # two steps: before the first auto-reset of the big run
+        for key in ('obs', 'next_obs', 'reward', 'absorbing'):
+            assert torch.equal(ref[key], out[key][:2, sl]), (key, sl)
+
+
 def test_mapping_census_matches_the_library():
     """Round 6: which lane mappings are instantiated is ONE rule (csrc/atacom_ops_impl.h: has_mapping); a request for a
     mapping that does not exist runs the widest narrower one and the handle SAYS so (float64 8-lane policy
